@@ -1,0 +1,161 @@
+/*
+ * stllm_hip.h — C ABI of libstllm_hip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * ST-LLM video-token hot path (EVA-CLIP-g ViT -> Q-Former -> projector -> Vicuna-7B prefill).
+ *
+ * The reference (TencentARC/ST-LLM) has NO native/FFI layer for this path:
+ * the arithmetic is torch.nn ops dispatched to vendor BLAS/DNN kernels.  Each entry point below
+ * therefore cites the reference torch call site(s) it replaces (paths relative to the reference
+ * root) rather than an existing FFI symbol.  The Python binding a maintainer would add is the
+ * ctypes stub in st-llm_amd/hip.py (shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  All data pointers are DEVICE pointers
+ *     owned by the caller (torch tensors in the shipped host code); nothing is allocated inside.
+ *   - every call takes the hipStream_t to launch on (void* here so the header needs no HIP include).
+ *   - return 0 on success, negative stllm_status on error; stllm_last_error() gives the message
+ *     (thread-local).  Kernels are launched asynchronously; launch errors are reported, execution
+ *     errors surface at the caller's next synchronisation as usual.
+ *   - "T" below is the compute dtype selected by `dtype`: bf16 / fp16 (MFMA 32x32x16, fp32
+ *     accumulate) or fp32 (exact-fp32 MFMA 32x32x2 — the "verify" numerics mode).
+ *   - the residual stream / normalisation inputs are always fp32 (SURVEY.md §7 hard-part 1).
+ *   - matrices are row-major; weights are [N, K] (out_features, in_features) exactly as
+ *     torch.nn.Linear stores them, possibly row-permuted by the packers in st-llm_amd/pack.py.
+ */
+#ifndef STLLM_HIP_H
+#define STLLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { STLLM_BF16 = 0, STLLM_F16 = 1, STLLM_F32 = 2 } stllm_dtype;
+
+typedef enum {
+  STLLM_OK = 0,
+  STLLM_ERR_BAD_SHAPE = -1,   /* size/stride/alignment constraint violated */
+  STLLM_ERR_BAD_DTYPE = -2,
+  STLLM_ERR_HIP = -3,         /* hip runtime error at launch */
+  STLLM_ERR_UNSUPPORTED = -4
+} stllm_status;
+
+/* GEMM epilogues (fused into the producing kernel) */
+typedef enum {
+  STLLM_EPI_STORE = 0,   /* out = act(acc + bias), out dtype T or f32                              */
+  STLLM_EPI_RESID = 1,   /* out_f32 = resid_f32 + acc + bias        (in place when out == resid)   */
+  STLLM_EPI_SWIGLU = 2,  /* out[:, j] = silu(gate_j) * up_j; W rows packed [32 gate | 32 up] x N/64 */
+  STLLM_EPI_ROPE = 3,    /* fused QKV: rotate-half RoPE on columns < rope_cols (packed layout)     */
+  STLLM_EPI_PATCH = 4    /* patch-embed: out_f32[n*257+1+p] = acc + bias + pos_embed[1+p]          */
+} stllm_epilogue;
+
+typedef enum { STLLM_ACT_NONE = 0, STLLM_ACT_GELU = 1, STLLM_ACT_RELU = 2 } stllm_act;
+
+const char* stllm_last_error(void);
+int stllm_abi_version(void);
+
+/*
+ * C[M,N] = epilogue(A[M,K] @ W[N,K]^T)  on MFMA, LDS-tiled (128-byte K panels, XOR-swizzled).
+ * Replaces every nn.Linear / F.linear on the path:
+ *   eva_vit.py:124 (qkv), :146 (proj), :55-59 (fc1/fc2); Qformer.py:186-198 (query/key/value),
+ *   :286 (attention output dense), :359 (intermediate), :372 (output); st_llm.py:368 (llama_proj),
+ *   :475 (down/up_proj), :38-42 (mvm_decoder.head), :122 (lm_head); HF LlamaAttention q/k/v/o_proj
+ *   and LlamaMLP gate/up/down_proj (spec: modeling_llama_mem.py:163-166, 138-144).
+ * Constraints: K*sizeof(T) % 128 == 0; N % 128 == 0; lda/ldw*sizeof(T) % 16 == 0; A, W 16-byte aligned.
+ * A: T[M,lda]   W: T[N,ldw]   bias: f32[N] or NULL
+ * STORE : out = T or f32 (out_is_f32) [M,ldo]; act = stllm_act
+ * RESID : resid/out f32 [M,ldo]
+ * SWIGLU: out T[M,ldo], N/2 columns
+ * ROPE  : out T[M,ldo]; rope_cos/rope_sin f32[rope_seq, 64]; row m is position m % rope_seq;
+ *         head_dim fixed at 128; columns >= rope_cols are stored unrotated
+ * PATCH : A is ignored — the A operand is gathered from `frames` f32 [n_frames,3,224,224]
+ *         (implicit GEMM, eva_vit.py:196-204); M = n_frames*256; K = 588 padded (W zero-padded to
+ *         ldw); out_f32 = x[n_frames*257, ldo]; `aux` = pos_embed f32[257,N].
+ */
+typedef struct {
+  int dtype;          /* stllm_dtype */
+  int epilogue;       /* stllm_epilogue */
+  int act;            /* stllm_act (STORE only) */
+  int out_is_f32;     /* STORE only */
+  const void* A; int64_t lda;
+  const void* W; int64_t ldw;
+  const float* bias;
+  void* out; int64_t ldo;
+  const float* resid; int64_t ldr;
+  const float* aux0;  /* ROPE: cos table; PATCH: pos_embed */
+  const float* aux1;  /* ROPE: sin table */
+  const float* frames;/* PATCH */
+  int rope_seq; int rope_cols;
+  int M, N, K;
+  /* optional 2-level row indexing (0 = flat): logical row m lives at
+   *   (m / rows_per_batch) * batch_stride + (m % rows_per_batch) * ld      [elements]
+   * used for the Q-Former's query / text row groups inside a [N, 32+Lt, C] buffer
+   * (Qformer.py:430-462 slices hidden states by query_length). */
+  int a_rows_per_batch; int64_t a_batch_stride;
+  int o_rows_per_batch; int64_t o_batch_stride;
+} stllm_gemm_args;
+int stllm_gemm(const stllm_gemm_args* args, void* stream);
+
+/*
+ * LayerNorm over the last dim of x f32[M,D] (ldx), fp32 statistics (two-pass), affine.
+ * Writes out_t T[M,D] (ldo_t) and/or out_f32 [M,D] (ldo_f); either may be NULL.
+ * Replaces nn.LayerNorm at eva_vit.py:157,163 (eps 1e-6), blip2.py:103-109 (ln_vision, eps 1e-5),
+ * Qformer.py:65,106,282,288,368,374 (eps 1e-12), st_llm.py:39 (mvm_decoder.norm).
+ * D % 4 == 0, D <= 8192.
+ */
+int stllm_layernorm(int dtype, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                    float eps, void* out_t, int64_t ldo_t, float* out_f32, int64_t ldo_f,
+                    int M, int D, void* stream);
+
+/* RMSNorm (HF LlamaRMSNorm, spec modeling_llama_mem.py:61-78): out = w * x * rsqrt(mean(x^2)+eps). */
+int stllm_rmsnorm(int dtype, const float* x, int64_t ldx, const float* gamma, float eps,
+                  void* out_t, int64_t ldo_t, float* out_f32, int64_t ldo_f, int M, int D, void* stream);
+
+/*
+ * Fused softmax(scale * Q K^T + mask) V, FlashAttention-style (online softmax, LDS-tiled K/V,
+ * MFMA 32x32x16; fp32 dtype uses an exact-fp32 vector kernel).  Never materialises S.
+ * Replaces eva_vit.py:128-145 (ViT, 16 heads x 88), Qformer.py:205-268 (self: 12x64, cross),
+ * HF LlamaAttention softmax(QK^T/sqrt(128) + causal/pad mask) V (spec modeling_llama_mem.py:172-248).
+ * q: T, element (b, s, h, d) at q[b*q_bs + s*q_rs + h*D + d]; same for k, v (Skv rows) and out.
+ * kv_len: int32[B] or NULL — keys >= kv_len[b] are masked (right-padding / Q-Former text mask,
+ *         Qformer.py:785-801 with -10000 == exact 0 after fp32 softmax).
+ * causal: key j visible to query i iff j <= i (Sq == Skv).
+ * D in {64, 88, 128}; all strides multiples of 8 elements; pointers 16-byte aligned.
+ */
+int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q_rs,
+                    const void* k, int64_t k_bs, int64_t k_rs,
+                    const void* v, int64_t v_bs, int64_t v_rs,
+                    void* out, int64_t o_bs, int64_t o_rs,
+                    int B, int H, int Sq, int Skv, int D, float scale, int causal,
+                    const int32_t* kv_len, void* stream);
+
+/*
+ * Row gather (token-block assembly, dynamic masking, residual-index selection, embedding lookup):
+ *   dst[i, :] = (idx_a[i] >= 0 ? src_a[idx_a[i], :] : src_b[-idx_a[i]-1, :]) + (add ? add[idx_add[i], :] : 0)
+ * all f32, D % 4 == 0.  Replaces torch.cat / index / embed_tokens glue at st_llm.py:391-404,
+ * 416-431, 473-476, 491, 509, 524-530 and conversation.py:288-293, 336-337.
+ */
+int stllm_gather_rows(const float* src_a, int64_t ld_a, const float* src_b, int64_t ld_b,
+                      const int32_t* idx_a, const float* add, int64_t ld_add, const int32_t* idx_add,
+                      float* dst, int64_t ld_dst, int n_rows, int D, void* stream);
+
+/* out[b, j] = mean_t x[b, t, j]  (x f32 [B,T,J] contiguous) — st_llm.py:468,471; conversation.py:282,287 */
+int stllm_mean_t(const float* x, float* out, int B, int T, int64_t J, void* stream);
+
+/* x[n*257, :] = cls_token + pos_embed[0]  for every frame — eva_vit.py:328-331 (CLS row) */
+int stllm_vit_cls_rows(const float* cls, const float* pos, float* x, int64_t ldx, int n_frames, int D,
+                       void* stream);
+
+/* MVM loss pieces (st_llm.py:89-91): out[i] = 2 - 2 * <a_i/|a_i|, b_i/|b_i|>, rows gathered by index */
+int stllm_cosine_rows(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
+                      const int32_t* idx_b, float* out, int n_rows, int D, void* stream);
+
+/* shifted-label cross entropy rows (st_llm.py:127-135): loss[i] = logsumexp(logits[i]) - logits[i,labels[i]];
+ * labels[i] < 0 (ignore_index) -> 0.  The caller averages over the valid rows. */
+int stllm_cross_entropy_rows(const float* logits, int64_t ldl, const int32_t* labels, float* loss,
+                             int n_rows, int V, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STLLM_HIP_H */

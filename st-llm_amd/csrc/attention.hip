@@ -1,0 +1,291 @@
+// Fused attention  out = softmax(scale * Q K^T + mask) V   (never materialises S)
+//
+// 16-bit path (bf16/fp16, MFMA 32x32x16, fp32 online softmax) — "everything transposed" layout:
+//   * a wave owns 32 query rows; a workgroup = NW waves = 32*NW rows of one (batch, head).
+//   * per 32-key tile:  S^T[kv][q] = K_tile[kv][d] . Q^T[d][q]      (A = K from LDS, B = Q in VGPRs)
+//     so every lane holds 16 scores of ONE query (q = lane & 31): row max / row sum are in-lane
+//     reductions plus a single lane<->lane+32 exchange (wave shuffles), no LDS round trip.
+//   * P^T stays in registers and is already in B-operand form for
+//                         O^T[d][q] += V^T[d][kv] . P^T[kv][q]       (A = V^T from LDS)
+//     the key<->k-slot map of the MFMA is free as long as A and B agree, so the S^T accumulator
+//     register order {0-3,8-11 | 4-7,12-15}+16a is used as the contraction order directly: V^T
+//     fragments are two 8-byte LDS reads at [d][16a+4h] and [d][16a+8+4h].
+//   * O^T columns are queries too, so the online-softmax rescale is an in-lane multiply.
+//   * K tile rows are padded by 16 B and V^T rows by 8 B: conflict-free ds_read_b128 / ds_read_b64.
+//   * head_dim 88 (EVA-CLIP-g) is zero-padded to 96 in LDS/registers only; HBM traffic stays 88.
+// fp32 path ("verify" numerics): exact-fp32 vector kernel, one wave per query row.
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const char* q; int64_t q_bs, q_rs;   // strides in elements
+  const char* k; int64_t k_bs, k_rs;
+  const char* v; int64_t v_bs, v_rs;
+  char* o; int64_t o_bs, o_rs;
+  int B, H, Sq, Skv, D;
+  float scale_log2;                     // scale * log2(e)
+  float scale;
+  int causal;
+  const int32_t* kv_len;
+};
+
+constexpr float kNeg = -1.0e30f;
+
+template <typename T, int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) {
+  constexpr int KS = DP / 16;          // k-steps of the S^T MFMA chain
+  constexpr int DB = DP / 32;          // 32-row blocks of O^T
+  constexpr int KPITCH = DP * 2 + 16;  // bytes per K row in LDS
+  constexpr int VPITCH = 32 * 2 + 8;   // bytes per V^T row in LDS
+  constexpr int NT = 64 * NW;
+  constexpr int CPR = DP / 8;          // 16-byte chunks per K/V row
+  constexpr int NCH = 32 * CPR;        // chunks per tile
+  constexpr int CPT = (NCH + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) char k_lds[32 * KPITCH];
+  __shared__ __attribute__((aligned(16))) char v_lds[DP * VPITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_blk0 = blockIdx.x * (32 * NW);
+  const int qrow = q_blk0 + wave * 32 + li;  // this lane's query
+  const int D = p.D;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+
+  // ---- Q fragments (B operand of S^T): lane holds Q[q][ks*16 + lh*8 .. +8] ------------------------
+  i32x4 qf[KS];
+  {
+    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + lh * 8;
+      i32x4 z = {0, 0, 0, 0};
+      qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
+    }
+  }
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+  float m_run = kNeg, l_run = 0.0f;
+
+  int kv_end = kvlen;
+  if (p.causal) kv_end = min(kv_end, q_blk0 + 32 * NW);  // keys beyond the last query of the block are masked
+  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
+  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
+
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
+    // ---- stage K tile (row-major, padded) and V tile (transposed) ---------------------------------
+    i32x4 kreg[CPT], vreg[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = tid + c * NT;
+      const int row = ch / CPR, cc = ch - row * CPR;
+      const int kv = kv0 + row;
+      const bool ok = (ch < NCH) && (kv < p.Skv) && (cc * 8 < D);
+      i32x4 z = {0, 0, 0, 0};
+      kreg[c] = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)kv * p.k_rs + cc * 8) * 2) : z;
+      vreg[c] = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)kv * p.v_rs + cc * 8) * 2) : z;
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = tid + c * NT;
+      if (ch < NCH) {
+        const int row = ch / CPR, cc = ch - row * CPR;
+        *reinterpret_cast<i32x4*>(k_lds + row * KPITCH + cc * 16) = kreg[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t w = (uint32_t)vreg[c][e];
+          *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + row * 2) = (uint16_t)(w & 0xffff);
+          *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + row * 2) = (uint16_t)(w >> 16);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T ------------------------------------------------------------------------------
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const i32x4 kf = *reinterpret_cast<const i32x4*>(k_lds + li * KPITCH + (ks * 2 + lh) * 16);
+      s = Elem<T>::mfma(kf, qf[ks], s);
+    }
+    // ---- mask + online softmax (per-lane query) ------------------------------------------------------
+    float mx = kNeg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float x = s[r] * p.scale_log2;
+      const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
+      x = dead ? kNeg : x;
+      s[r] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = exp2f(s[r] - m_new);
+      s[r] = pv;
+      rs += pv;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      i32x4 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pf[e] = (int)((uint32_t)Elem<T>::pack(s[a * 8 + 2 * e]) | ((uint32_t)Elem<T>::pack(s[a * 8 + 2 * e + 1]) << 16));
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+        const char* vp = v_lds + (i * 32 + li) * VPITCH + (16 * a + 4 * lh) * 2;
+        const i32x2 lo = *reinterpret_cast<const i32x2*>(vp);
+        const i32x2 hi = *reinterpret_cast<const i32x2*>(vp + 16);
+        const i32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+        o[i] = Elem<T>::mfma(vf, pf, o[i]);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q][d = i*32 + (r&3) + 8*(r>>2) + 4*lh] ------------------------
+  if (qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * lh;
+        if (d0 < D) {  // D % 4 == 0
+          uint2 pk;
+          pk.x = (uint32_t)Elem<T>::pack(o[i][4 * g + 0] * inv) | ((uint32_t)Elem<T>::pack(o[i][4 * g + 1] * inv) << 16);
+          pk.y = (uint32_t)Elem<T>::pack(o[i][4 * g + 2] * inv) | ((uint32_t)Elem<T>::pack(o[i][4 * g + 3] * inv) << 16);
+          *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
+      }
+    }
+  }
+}
+
+// ---- exact fp32 path: one wave per query row -----------------------------------------------------
+constexpr int kF32MaxKv = 2048;
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
+  __shared__ float q_s[4][128];
+  __shared__ float sc[4][kF32MaxKv];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qrow = blockIdx.x * 4 + w;
+  if (qrow >= p.Sq) return;  // no block-level sync below
+  const int D = p.D;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int kv_end = p.causal ? min(kvlen, qrow + 1) : kvlen;
+  const float* q = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * D;
+  const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.k_bs + (int64_t)h * D;
+  const float* vb = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.v_bs + (int64_t)h * D;
+  for (int d = lane; d < D; d += 64) q_s[w][d] = q[d];
+  __builtin_amdgcn_wave_barrier();
+  float mx = kNeg;
+  for (int j = lane; j < kv_end; j += 64) {
+    const float4* kr = reinterpret_cast<const float4*>(kb + (int64_t)j * p.k_rs);
+    float acc = 0.0f;
+    for (int d4 = 0; d4 < (D >> 2); ++d4) {
+      const float4 kk = kr[d4];
+      acc = fmaf(q_s[w][4 * d4 + 0], kk.x, acc);
+      acc = fmaf(q_s[w][4 * d4 + 1], kk.y, acc);
+      acc = fmaf(q_s[w][4 * d4 + 2], kk.z, acc);
+      acc = fmaf(q_s[w][4 * d4 + 3], kk.w, acc);
+    }
+    acc *= p.scale;
+    sc[w][j] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  mx = wave_max(mx);
+  float sum = 0.0f;
+  for (int j = lane; j < kv_end; j += 64) {
+    const float e = expf(sc[w][j] - mx);
+    sc[w][j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.0f / sum;
+  float* o = reinterpret_cast<float*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.0f;
+    for (int j = 0; j < kv_end; ++j) acc = fmaf(sc[w][j], vb[(int64_t)j * p.v_rs + d], acc);
+    o[d] = acc * inv;
+  }
+}
+
+template <typename T, int DP, int NW>
+int launch_mfma(const AttnParams& p, hipStream_t stream) {
+  dim3 grid((p.Sq + 32 * NW - 1) / (32 * NW), p.H, p.B), block(64 * NW);
+  hipLaunchKernelGGL((attn_mfma_kernel<T, DP, NW>), grid, block, 0, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention");
+  return STLLM_OK;
+}
+
+template <typename T>
+int dispatch(const AttnParams& p, hipStream_t stream) {
+  // NW picked so that 32*NW divides the common sequence lengths with little waste:
+  //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
+  if (p.D == 88) return launch_mfma<T, 96, 3>(p, stream);
+  if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
+  if (p.D == 128) return launch_mfma<T, 128, 3>(p, stream);
+  stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
+  return STLLM_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs,
+                               int64_t k_rs, const void* v, int64_t v_bs, int64_t v_rs, void* out, int64_t o_bs,
+                               int64_t o_rs, int B, int H, int Sq, int Skv, int D, float scale, int causal,
+                               const int32_t* kv_len, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  STLLM_CHECK_ARG(q && k && v && out, "stllm_attention: null pointer");
+  STLLM_CHECK_ARG(B > 0 && H > 0 && Sq > 0 && Skv > 0, "stllm_attention: empty problem");
+  STLLM_CHECK_ARG(D == 64 || D == 88 || D == 128, "stllm_attention: head_dim %d not in {64,88,128}", D);
+  STLLM_CHECK_ARG(!causal || Sq == Skv, "stllm_attention: causal needs Sq == Skv");
+  STLLM_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out), "stllm_attention: pointers must be 16-byte aligned");
+  STLLM_CHECK_ARG(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+                      v_bs % 8 == 0 && o_bs % 8 == 0, "stllm_attention: strides must be multiples of 8 elements");
+  AttnParams p{};
+  p.q = (const char*)q; p.q_bs = q_bs; p.q_rs = q_rs;
+  p.k = (const char*)k; p.k_bs = k_bs; p.k_rs = k_rs;
+  p.v = (const char*)v; p.v_bs = v_bs; p.v_rs = v_rs;
+  p.o = (char*)out; p.o_bs = o_bs; p.o_rs = o_rs;
+  p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+  p.scale = scale; p.scale_log2 = scale * 1.44269504088896340736f;
+  p.causal = causal; p.kv_len = kv_len;
+  switch (dtype) {
+    case STLLM_BF16: return dispatch<bf16_t>(p, stream);
+    case STLLM_F16: return dispatch<f16_t>(p, stream);
+    case STLLM_F32: {
+      STLLM_CHECK_ARG(Skv <= kF32MaxKv, "stllm_attention(fp32): Skv %d > %d", Skv, kF32MaxKv);
+      dim3 grid((Sq + 3) / 4, H, B), block(256);
+      hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, stream, p);
+      STLLM_CHECK_LAUNCH("stllm_attention(fp32)");
+      return STLLM_OK;
+    }
+  }
+  stllm_set_error("stllm_attention: bad dtype %d", dtype);
+  return STLLM_ERR_BAD_DTYPE;
+}

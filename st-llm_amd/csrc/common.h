@@ -1,0 +1,135 @@
+// Shared device/host helpers for libstllm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/stllm_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// host: error plumbing
+// ---------------------------------------------------------------------------------------------
+void stllm_set_error(const char* fmt, ...);
+
+#define STLLM_CHECK_ARG(cond, ...)                 \
+  do {                                             \
+    if (!(cond)) {                                 \
+      stllm_set_error(__VA_ARGS__);                \
+      return STLLM_ERR_BAD_SHAPE;                  \
+    }                                              \
+  } while (0)
+
+#define STLLM_CHECK_LAUNCH(what)                                                   \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      stllm_set_error("%s: HIP launch error: %s", what, hipGetErrorString(e_));    \
+      return STLLM_ERR_HIP;                                                        \
+    }                                                                              \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// device: vector types
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+struct bf16_t { uint16_t v; };   // tag types for templates (storage = 2 bytes)
+struct f16_t { uint16_t v; };
+
+// fp32 -> bf16 round-to-nearest-even (matches torch .to(bfloat16))
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+  return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;  // v_cvt_f16_f32, RNE
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr bool kIsF32 = false;
+  __device__ static __forceinline__ uint16_t pack(float f) { return f32_to_bf16_bits(f); }
+  __device__ static __forceinline__ float unpack(uint16_t h) { return bf16_bits_to_f32(h); }
+  __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Elem<f16_t> {
+  static constexpr int kBytes = 2;
+  static constexpr bool kIsF32 = false;
+  __device__ static __forceinline__ uint16_t pack(float f) { return f32_to_f16_bits(f); }
+  __device__ static __forceinline__ float unpack(uint16_t h) { return f16_bits_to_f32(h); }
+  __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Elem<float> {
+  static constexpr int kBytes = 4;
+  static constexpr bool kIsF32 = true;
+  // One 16-byte fragment = 4 consecutive k of this lane's half; the k <-> (step, half) slot map is
+  // the same for A and B, so 4 exact-fp32 MFMAs (K=2 each) consume one fragment pair.
+  __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// store one value of the compute dtype
+template <typename T> __device__ __forceinline__ void store_elem(void* base, int64_t idx, float v) {
+  if constexpr (Elem<T>::kIsF32) reinterpret_cast<float*>(base)[idx] = v;
+  else reinterpret_cast<uint16_t*>(base)[idx] = Elem<T>::pack(v);
+}
+template <typename T> __device__ __forceinline__ float load_elem(const void* base, int64_t idx) {
+  if constexpr (Elem<T>::kIsF32) return reinterpret_cast<const float*>(base)[idx];
+  else return Elem<T>::unpack(reinterpret_cast<const uint16_t*>(base)[idx]);
+}
+
+// async global -> LDS, 16 bytes per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// exact-erf GELU (nn.GELU()): erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
+__device__ __forceinline__ float erf_as(float x) {
+  float ax = fabsf(x);
+  float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  float r = 1.0f - p * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,124 @@
+// LayerNorm / RMSNorm over fp32 rows: HBM-bound streaming kernels.
+// One wave per row, row cached in registers (float4 per lane per step), fp32 two-pass statistics
+// via wave shuffles; writes the compute-dtype copy (next GEMM's A operand) and/or an fp32 copy.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxVec = 32;  // D <= 64 lanes * 4 floats * 32 = 8192
+
+template <typename T, bool RMS, int NV>
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float eps, void* __restrict__ out_t, int64_t ldo_t,
+                                                   float* __restrict__ out_f, int64_t ldo_f, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+  float4 v[NV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    else s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  s = wave_sum(s);
+  float mean = 0.0f, rstd;
+  if constexpr (RMS) {
+    rstd = rsqrtf(s / (float)D + eps);
+  } else {
+    mean = s / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+    }
+    q = wave_sum(q);
+    rstd = rsqrtf(q / (float)D + eps);
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c >= nvec) continue;
+    const float4 g = g4[c];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x; o.y = (v[i].y - mean) * rstd * g.y;
+    o.z = (v[i].z - mean) * rstd * g.z; o.w = (v[i].w - mean) * rstd * g.w;
+    if constexpr (!RMS) {
+      const float4 b = b4[c];
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
+    if (out_t) {
+      if constexpr (Elem<T>::kIsF32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
+      } else {
+        uint2 pk;
+        pk.x = (uint32_t)Elem<T>::pack(o.x) | ((uint32_t)Elem<T>::pack(o.y) << 16);
+        pk.y = (uint32_t)Elem<T>::pack(o.z) | ((uint32_t)Elem<T>::pack(o.w) << 16);
+        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
+      }
+    }
+  }
+}
+
+template <typename T, bool RMS>
+int launch_nv(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out_t,
+              int64_t ldo_t, float* out_f, int64_t ldo_f, int M, int D, hipStream_t stream) {
+  const int nv = ((D >> 2) + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+#define STLLM_NORM_CASE(NV)                                                                                  \
+  hipLaunchKernelGGL((norm_kernel<T, RMS, NV>), grid, block, 0, stream, x, ldx, gamma, beta, eps, out_t, ldo_t, \
+                     out_f, ldo_f, M, D)
+  if (nv <= 3) STLLM_NORM_CASE(3);
+  else if (nv <= 6) STLLM_NORM_CASE(6);
+  else if (nv <= 16) STLLM_NORM_CASE(16);
+  else STLLM_NORM_CASE(kMaxVec);
+#undef STLLM_NORM_CASE
+  STLLM_CHECK_LAUNCH(RMS ? "stllm_rmsnorm" : "stllm_layernorm");
+  return STLLM_OK;
+}
+
+template <bool RMS>
+int norm_entry(int dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+               void* out_t, int64_t ldo_t, float* out_f, int64_t ldo_f, int M, int D, hipStream_t stream) {
+  const char* nm = RMS ? "stllm_rmsnorm" : "stllm_layernorm";
+  STLLM_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * kMaxVec, "%s: bad M=%d D=%d", nm, M, D);
+  STLLM_CHECK_ARG(x && gamma && (RMS || beta), "%s: null input", nm);
+  STLLM_CHECK_ARG(out_t || out_f, "%s: no output requested", nm);
+  STLLM_CHECK_ARG(ldx % 4 == 0 && aligned16(x) && aligned16(gamma), "%s: x/gamma not 16-byte aligned", nm);
+  if (out_f) STLLM_CHECK_ARG(ldo_f % 4 == 0 && aligned16(out_f), "%s: out_f32 misaligned", nm);
+  if (out_t) STLLM_CHECK_ARG(ldo_t % 4 == 0 && (reinterpret_cast<uintptr_t>(out_t) & 7) == 0, "%s: out_t misaligned", nm);
+  switch (dtype) {
+    case STLLM_BF16: return launch_nv<bf16_t, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
+    case STLLM_F16: return launch_nv<f16_t, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
+    case STLLM_F32: return launch_nv<float, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
+  }
+  stllm_set_error("%s: bad dtype %d", nm, dtype);
+  return STLLM_ERR_BAD_DTYPE;
+}
+
+}  // namespace
+
+extern "C" int stllm_layernorm(int dtype, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                               float eps, void* out_t, int64_t ldo_t, float* out_f32, int64_t ldo_f, int M,
+                               int D, void* stream) {
+  return norm_entry<false>(dtype, x, ldx, gamma, beta, eps, out_t, ldo_t, out_f32, ldo_f, M, D,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int stllm_rmsnorm(int dtype, const float* x, int64_t ldx, const float* gamma, float eps, void* out_t,
+                             int64_t ldo_t, float* out_f32, int64_t ldo_f, int M, int D, void* stream) {
+  return norm_entry<true>(dtype, x, ldx, gamma, nullptr, eps, out_t, ldo_t, out_f32, ldo_f, M, D,
+                          reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,249 @@
+"""ctypes binding of libstllm_hip.so (include/stllm_hip.h) for torch tensors.
+
+This is plumbing only: torch owns device memory and streams; every function here hands raw
+``data_ptr()``s and the current HIP stream to the C ABI.  There is NO fallback: if the shared
+library is missing or a call fails, a RuntimeError is raised (a product path that silently ran
+on eager PyTorch would void every parity claim).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+BF16, F16, F32 = 0, 1, 2
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_ROPE, EPI_PATCH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+_DT = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
+_NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
+          "bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}
+
+EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
+           "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
+           "stllm_cross_entropy_rows"]
+
+
+def torch_dtype(d):
+    return _NAMES[d] if isinstance(d, str) else d
+
+
+def dtype_code(d):
+    return _DT[torch_dtype(d)]
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("epilogue", c_int), ("act", c_int), ("out_is_f32", c_int),
+                ("A", c_void_p), ("lda", c_int64), ("W", c_void_p), ("ldw", c_int64),
+                ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int64),
+                ("resid", c_void_p), ("ldr", c_int64),
+                ("aux0", c_void_p), ("aux1", c_void_p), ("frames", c_void_p),
+                ("rope_seq", c_int), ("rope_cols", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
+                ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64)]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")
+_lib = None
+
+
+def lib():
+    """Load libstllm_hip.so (built in-tree by stllm_amd.build / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found — run `python __graft_entry__.py` (build()) first; "
+                               "there is no CPU/eager fallback for the HIP path")
+        L = ctypes.CDLL(LIB_PATH)
+        L.stllm_last_error.restype = c_char_p
+        L.stllm_abi_version.restype = c_int
+        L.stllm_gemm.argtypes = [ctypes.POINTER(GemmArgs), c_void_p]
+        L.stllm_layernorm.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_int, c_int, c_void_p]
+        L.stllm_rmsnorm.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_int, c_int, c_void_p]
+        L.stllm_attention.argtypes = [c_int] + [c_void_p, c_int64, c_int64] * 4 + [c_int] * 5 + [c_float, c_int,
+                                                                                              c_void_p, c_void_p]
+        L.stllm_gather_rows.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                        c_void_p, c_int64, c_int, c_int, c_void_p]
+        L.stllm_mean_t.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]
+        L.stllm_vit_cls_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]
+        L.stllm_cosine_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                        c_int, c_void_p]
+        L.stllm_cross_entropy_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]
+        for n in EXPORTS[2:]:
+            getattr(L, n).restype = c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib().stllm_last_error().decode()}")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _req(t, dtype=None, what="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must be a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{what}: expected {dtype}, got {t.dtype}")
+    if t.dim() >= 1 and t.stride(-1) != 1:
+        raise RuntimeError(f"{what}: last dim must be contiguous")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
+         rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
+         a_rows=None, o_rows=None):
+    """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded)."""
+    td = torch_dtype(dtype)
+    args = GemmArgs()
+    args.dtype, args.epilogue, args.act, args.out_is_f32 = dtype_code(td), epilogue, act, int(out_f32)
+    _req(w, td, "W")
+    N = w.shape[0]
+    if epilogue == EPI_PATCH:
+        M, K = n_frames * 256, 588
+        _req(frames, torch.float32, "frames"); _req(pos_embed, torch.float32, "pos_embed")
+        args.frames, args.aux0 = _p(frames), _p(pos_embed)
+        args.A, args.lda = None, 0
+    else:
+        _req(a, td, "A")
+        K = a.shape[-1]
+        if a_rows is not None:  # (rows_per_batch, batch_stride): 2-level rows inside a larger buffer
+            args.a_rows_per_batch, args.a_batch_stride = a_rows
+            if M is None:
+                raise RuntimeError("gemm: M is required with a_rows")
+        elif M is None:
+            M = a.shape[0]
+        args.A, args.lda = _p(a), a.stride(-2)
+    args.W, args.ldw = _p(w), w.stride(0)
+    if bias is not None:
+        _req(bias, torch.float32, "bias")
+    args.bias = _p(bias)
+    if epilogue == EPI_RESID:
+        _req(resid, torch.float32, "resid")
+        out = resid if out is None else out
+        _req(out, torch.float32, "out")
+        args.resid, args.ldr = _p(resid), resid.stride(-2)
+    elif epilogue == EPI_PATCH:
+        _req(out, torch.float32, "out")
+    else:
+        n_out = N // 2 if epilogue == EPI_SWIGLU else N
+        if out is None:
+            out = torch.empty((M, n_out), device=w.device, dtype=torch.float32 if out_f32 else td)
+        _req(out, torch.float32 if out_f32 else td, "out")
+    if epilogue == EPI_ROPE:
+        cos, sin = rope
+        _req(cos, torch.float32, "rope cos"); _req(sin, torch.float32, "rope sin")
+        args.aux0, args.aux1, args.rope_seq, args.rope_cols = _p(cos), _p(sin), rope_seq, rope_cols
+    if o_rows is not None:
+        args.o_rows_per_batch, args.o_batch_stride = o_rows
+    args.out, args.ldo = _p(out), out.stride(-2)
+    args.M, args.N, args.K = M, N, K
+    _check(lib().stllm_gemm(ctypes.byref(args), _stream()), "stllm_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
+    """x f32 [M,D] -> (out_t compute-dtype [M,D] | None, out_f32 | None)."""
+    _req(x, torch.float32, "x")
+    M, D = x.shape
+    td = torch_dtype(dtype)
+    if want_t and out_t is None:
+        out_t = torch.empty((M, D), device=x.device, dtype=td)
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty((M, D), device=x.device, dtype=torch.float32)
+    _check(lib().stllm_layernorm(dtype_code(td), _p(x), x.stride(0), _p(gamma), _p(beta), eps,
+                                 _p(out_t), out_t.stride(0) if out_t is not None else 0,
+                                 _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0, M, D, _stream()),
+           "stllm_layernorm")
+    return out_t, out_f32
+
+
+def rmsnorm(x, gamma, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
+    _req(x, torch.float32, "x")
+    M, D = x.shape
+    td = torch_dtype(dtype)
+    if want_t and out_t is None:
+        out_t = torch.empty((M, D), device=x.device, dtype=td)
+    if want_f32 and out_f32 is None:
+        out_f32 = torch.empty((M, D), device=x.device, dtype=torch.float32)
+    _check(lib().stllm_rmsnorm(dtype_code(td), _p(x), x.stride(0), _p(gamma), eps,
+                               _p(out_t), out_t.stride(0) if out_t is not None else 0,
+                               _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0, M, D, _stream()),
+           "stllm_rmsnorm")
+    return out_t, out_f32
+
+
+def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, out=None,
+              q_strides=None, k_strides=None, v_strides=None):
+    """q/k/v: 2-D views [B*S, >=H*D] of the compute dtype (may be column slices of a fused QKV buffer).
+    *_strides = (batch_stride, row_stride) in elements; default: rows of one batch are consecutive."""
+    td = q.dtype
+
+    def st(t, S, given):
+        return given if given is not None else (S * t.stride(0), t.stride(0))
+    qs, ks, vs = st(q, Sq, q_strides), st(k, Skv, k_strides), st(v, Skv, v_strides)
+    if out is None:
+        out = torch.empty((B * Sq, H * D), device=q.device, dtype=td)
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len")
+    _check(lib().stllm_attention(dtype_code(td), _p(q), qs[0], qs[1], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1],
+                                 _p(out), Sq * out.stride(0), out.stride(0), B, H, Sq, Skv, D, scale, int(causal),
+                                 _p(kv_len), _stream()), "stllm_attention")
+    return out
+
+
+def gather_rows(src_a, idx_a, *, src_b=None, add=None, idx_add=None, out=None):
+    """out[i] = (idx_a[i] >= 0 ? src_a[idx_a[i]] : src_b[-idx_a[i]-1]) (+ add[idx_add[i]])."""
+    _req(src_a, torch.float32, "src_a"); _req(idx_a, torch.int32, "idx_a")
+    n, D = idx_a.numel(), src_a.shape[-1]
+    if out is None:
+        out = torch.empty((n, D), device=src_a.device, dtype=torch.float32)
+    _check(lib().stllm_gather_rows(_p(src_a), src_a.stride(0), _p(src_b), src_b.stride(0) if src_b is not None else 0,
+                                   _p(idx_a), _p(add), add.stride(0) if add is not None else 0, _p(idx_add),
+                                   _p(out), out.stride(0), n, D, _stream()), "stllm_gather_rows")
+    return out
+
+
+def mean_t(x):
+    """x f32 [B,T,...] contiguous -> mean over dim 1."""
+    _req(x, torch.float32, "x")
+    x = x.contiguous()
+    B, T = x.shape[0], x.shape[1]
+    J = x[0, 0].numel()
+    out = torch.empty((B,) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    _check(lib().stllm_mean_t(_p(x), _p(out), B, T, J, _stream()), "stllm_mean_t")
+    return out
+
+
+def vit_cls_rows(cls, pos, x, n_frames):
+    _check(lib().stllm_vit_cls_rows(_p(cls), _p(pos), _p(x), x.stride(0), n_frames, x.shape[-1], _stream()),
+           "stllm_vit_cls_rows")
+
+
+def cosine_rows(a, b, idx_a=None, idx_b=None, n_rows=None):
+    n = n_rows if n_rows is not None else (idx_a.numel() if idx_a is not None else a.shape[0])
+    out = torch.empty((n,), device=a.device, dtype=torch.float32)
+    _check(lib().stllm_cosine_rows(_p(a), a.stride(0), _p(idx_a), _p(b), b.stride(0), _p(idx_b), _p(out), n,
+                                   a.shape[-1], _stream()), "stllm_cosine_rows")
+    return out
+
+
+def cross_entropy_rows(logits, labels):
+    """logits f32 [n,V], labels int32 [n] (already shifted; <0 = ignore) -> per-row loss f32 [n]."""
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int32, "labels")
+    n, V = logits.shape
+    out = torch.empty((n,), device=logits.device, dtype=torch.float32)
+    _check(lib().stllm_cross_entropy_rows(_p(logits), logits.stride(0), _p(labels), _p(out), n, V, _stream()),
+           "stllm_cross_entropy_rows")
+    return out

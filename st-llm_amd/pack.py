@@ -1,0 +1,99 @@
+"""Weight packers: reference-named fp32 parameters -> the layouts the HIP kernels consume.
+
+All packers are pure index permutations / concatenations / casts (done once, on the device the
+parameter lives on); none changes the mathematical function:
+
+* ``vit_qkv_bias``   — eva_vit.py:120-124: bias = cat(q_bias, zeros, v_bias).
+* ``patch_weight``   — Conv2d weight [1408,3,14,14] -> GEMM weight [1408, 588] zero-padded in K to a
+                       whole number of 128-byte LDS panels (640 for 16-bit, 608 for fp32).
+* ``llama_qkv``      — q/k/v_proj fused to one [3*4096, 4096] weight.  Inside every 128-wide q/k head
+                       the rows are re-ordered to [0:32 | 64:96 | 32:64 | 96:128] so that the rotate-half
+                       partners (i, i+64) land in the two 32-column halves of one 64-column wave tile
+                       and RoPE is an in-lane epilogue.  q and k get the SAME permutation, so q.k is
+                       unchanged (spec of the rotation: modeling_llama_mem.py:113-127).
+* ``llama_gate_up``  — gate/up_proj interleaved in groups of 32 rows ([32 gate | 32 up] per 64-column
+                       wave tile) for the fused SiLU(gate)*up epilogue (modeling_llama_mem.py:143-144).
+* ``bert_qkv`` / ``bert_kv`` — Q-Former query/key/value fused (Qformer.py:127-133).
+"""
+import torch
+
+from .hip import torch_dtype
+
+
+def _cast(w, dtype):
+    return w.detach().to(torch_dtype(dtype)).contiguous()
+
+
+def linear(w, dtype):
+    return _cast(w, dtype)
+
+
+def f32(b):
+    return None if b is None else b.detach().float().contiguous()
+
+
+def vit_qkv_bias(q_bias, v_bias):
+    return torch.cat((q_bias.detach().float(), torch.zeros_like(v_bias, dtype=torch.float32), v_bias.detach().float())).contiguous()
+
+
+def patch_k_padded(dtype):
+    eb = 4 if torch_dtype(dtype) == torch.float32 else 2
+    panel = 128 // eb
+    return ((588 + panel - 1) // panel) * panel
+
+
+def patch_weight(w, dtype):
+    n = w.shape[0]
+    out = torch.zeros((n, patch_k_padded(dtype)), device=w.device, dtype=torch_dtype(dtype))
+    out[:, :588] = w.detach().reshape(n, 588).to(out.dtype)
+    return out
+
+
+def rope_head_perm(n_heads, head_dim=128, device="cpu"):
+    assert head_dim == 128
+    base = torch.cat([torch.arange(0, 32), torch.arange(64, 96), torch.arange(32, 64), torch.arange(96, 128)])
+    return (torch.arange(n_heads)[:, None] * head_dim + base[None, :]).reshape(-1).to(device)
+
+
+def llama_qkv(wq, wk, wv, dtype, n_heads=32):
+    perm = rope_head_perm(n_heads, wq.shape[0] // n_heads, wq.device)
+    return torch.cat((_cast(wq, dtype)[perm], _cast(wk, dtype)[perm], _cast(wv, dtype)), dim=0).contiguous()
+
+
+def llama_gate_up(wg, wu, dtype):
+    n, k = wg.shape
+    assert n % 32 == 0
+    g = _cast(wg, dtype).view(n // 32, 32, k)
+    u = _cast(wu, dtype).view(n // 32, 32, k)
+    return torch.stack((g, u), dim=1).reshape(2 * n, k).contiguous()
+
+
+def bert_qkv(q, k, v, dtype):
+    w = torch.cat((_cast(q.weight, dtype), _cast(k.weight, dtype), _cast(v.weight, dtype)), dim=0).contiguous()
+    b = torch.cat((f32(q.bias), f32(k.bias), f32(v.bias))).contiguous()
+    return w, b
+
+
+def bert_kv(k, v, dtype):
+    w = torch.cat((_cast(k.weight, dtype), _cast(v.weight, dtype)), dim=0).contiguous()
+    b = torch.cat((f32(k.bias), f32(v.bias))).contiguous()
+    return w, b
+
+
+def pad_rows(w, mult=128):
+    """zero-pad the out_features dim to a multiple of `mult` (lm_head with a 32001-token vocab)."""
+    n = w.shape[0]
+    n_pad = ((n + mult - 1) // mult) * mult
+    if n_pad == n:
+        return w
+    out = torch.zeros((n_pad,) + tuple(w.shape[1:]), device=w.device, dtype=w.dtype)
+    out[:n] = w
+    return out
+
+
+def rope_tables(S, head_dim=128, base=10000.0, device="cpu"):
+    """cos/sin [S, head_dim/2] fp32 — LlamaRotaryEmbedding (modeling_llama_mem.py:81-110); computed on the
+    host in fp32 exactly as the reference does, then copied to the device."""
+    inv = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    f = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+    return f.cos().contiguous().to(device), f.sin().contiguous().to(device)

@@ -1,0 +1,312 @@
+"""GPU: every HIP kernel behind the C ABI against a plain fp32/fp64 torch reference of the same op.
+
+Inputs are rounded to the compute dtype first, so the only differences are fp32 accumulation order
+and the final rounding of the output dtype:
+    out_f32 epilogues:  |err| <= 1e-4 * max|ref|     (catches any MFMA-layout / swizzle / tiling bug)
+    bf16 outputs:       |err| <= 2^-8  * max|ref|     (one bf16 rounding, 2^-9 relative, + slack)
+    fp16 outputs:       |err| <= 2^-10 * max|ref|
+    fp32 ("verify") dtype: |err| <= 2e-5 * max|ref|
+Data are asymmetric random (guide rule 16: transpose-detecting)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import stllm_oracle as O
+from _util import T
+
+pytestmark = pytest.mark.gpu
+DT = ["bf16", "fp16", "fp32"]
+OUT_TOL = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -10, "fp32": 2e-5}
+ACC_TOL = {"bf16": 1e-4, "fp16": 1e-4, "fp32": 2e-5}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from stllm_amd import hip as h
+    h.lib()
+    return h
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rnd(name, shape, dtype, std=1.0):
+    """random tensor rounded to compute dtype; returns (device tensor in dtype, fp64 CPU copy of the rounded values)"""
+    from stllm_amd.hip import torch_dtype
+    x = T(name, shape, std).to(torch_dtype(dtype))
+    return x.cuda(), x.double()
+
+
+def check(got, ref, tol, what):
+    got = got.detach().double().cpu()
+    ref = ref.double()
+    assert got.shape == ref.shape, f"{what}: {got.shape} vs {ref.shape}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:.1e} * {scale:.3e}"
+
+
+GEMM_SHAPES = [  # (M, N, K): ragged M, every tile path (64x64 small-problem path and 128x128)
+    (307, 384, 1408), (64, 128, 768), (33, 256, 128), (1100, 2304, 768), (4112 // 4, 4224, 1408)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_store(hip, dtype, M, N, K):
+    a, a64 = rnd("a", (M, K), dtype)
+    w, w64 = rnd("w", (N, K), dtype, 0.05)
+    b = T("b", (N,), 0.5)
+    ref = a64 @ w64.t() + b.double()
+    out32 = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+    check(out32, ref, ACC_TOL[dtype], "gemm f32 out")
+    out = hip.gemm(a, w, dtype=dtype, bias=b.cuda())
+    check(out, ref, OUT_TOL[dtype], "gemm T out")
+    nob = hip.gemm(a, w, dtype=dtype, out_f32=True)
+    check(nob, a64 @ w64.t(), ACC_TOL[dtype], "gemm no bias")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_identity_asymmetric(hip, dtype):
+    """A = I picks out W^T exactly: any row/col swap or lane mis-map shows up bit-exactly."""
+    K = N = 256
+    from stllm_amd.hip import torch_dtype
+    a = torch.eye(K, dtype=torch_dtype(dtype)).cuda()
+    w, w64 = rnd("w_asym", (N, K), dtype)
+    out = hip.gemm(a, w, dtype=dtype, out_f32=True)
+    assert torch.equal(out.cpu().double(), w64.t())
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_gemm_act(hip, dtype, act):
+    M, N, K = 300, 6144 // 4, 1408
+    a, a64 = rnd("a", (M, K), dtype)
+    w, w64 = rnd("w", (N, K), dtype, 0.03)
+    b = T("b", (N,), 0.2)
+    pre = a64 @ w64.t() + b.double()
+    ref = O.gelu(pre) if act == "gelu" else torch.relu(pre)
+    out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU if act == "gelu" else hip.ACT_RELU, out_f32=True)
+    check(out, ref, max(ACC_TOL[dtype], 3e-6), f"gemm {act}")  # erf by A&S 7.1.26, 1.5e-7 abs
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_resid(hip, dtype):
+    M, N, K = 515, 1408, 6144 // 2
+    a, a64 = rnd("a", (M, K), dtype)
+    w, w64 = rnd("w", (N, K), dtype, 0.02)
+    b = T("b", (N,), 0.2)
+    x = T("x", (M, N), 2.0)
+    ref = x.double() + a64 @ w64.t() + b.double()
+    xd = x.cuda()
+    out = torch.empty_like(xd)
+    hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd, out=out)
+    check(out, ref, ACC_TOL[dtype], "resid out-of-place")
+    hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)  # in place
+    check(xd, ref, ACC_TOL[dtype], "resid in-place")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M", [50, 333])
+def test_gemm_swiglu(hip, dtype, M):
+    from stllm_amd import pack
+    K, I = 512, 1024 + 128 * 3
+    a, a64 = rnd("a", (M, K), dtype)
+    wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+    wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+    ref = F.silu(a64 @ wg64.t()) * (a64 @ wu64.t())
+    out = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
+    check(out, ref, OUT_TOL[dtype], "swiglu")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_rope_qkv(hip, dtype):
+    """fused QKV + rotate-half RoPE in the packed head layout: q.k^T per head must equal the
+    reference's (the packing permutes q and k identically), v must be untouched."""
+    from stllm_amd import pack
+    B, S, H, D = 2, 37, 4, 128
+    K = 512
+    a, a64 = rnd("a", (B * S, K), dtype)
+    wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+    wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+    wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+    cos, sin = pack.rope_tables(S)
+    qkv = hip.gemm(a, pack.llama_qkv(wq, wk, wv, dtype, n_heads=H), dtype=dtype, epilogue=hip.EPI_ROPE,
+                   rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D)
+    qkv = qkv.double().cpu().view(B, S, 3, H, D)
+    c, s = O.rope_tables(S, D)
+    q = (a64 @ wq64.t()).view(B, S, H, D).transpose(1, 2)
+    k = (a64 @ wk64.t()).view(B, S, H, D).transpose(1, 2)
+    v = (a64 @ wv64.t()).view(B, S, H, D)
+    q = q * c.double() + O._rotate_half(q) * s.double()
+    k = k * c.double() + O._rotate_half(k) * s.double()
+    tol = OUT_TOL[dtype]
+    check(qkv[:, :, 2], v, tol, "v passthrough")
+    perm = pack.rope_head_perm(1)
+    check(qkv[:, :, 0].transpose(1, 2), q[..., perm], tol, "q rope (packed order)")
+    check(qkv[:, :, 1].transpose(1, 2), k[..., perm], tol, "k rope (packed order)")
+    got_s = qkv[:, :, 0].transpose(1, 2) @ qkv[:, :, 1].transpose(1, 2).transpose(-1, -2)
+    check(got_s, q @ k.transpose(-1, -2), 4 * tol, "q.k^T invariance")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_patch_embed(hip, dtype):
+    from stllm_amd import pack
+    from stllm_amd.hip import torch_dtype
+    n = 3
+    frames = T("input.frames", (n, 3, 224, 224))
+    w = T("pw", (1408, 3, 14, 14), 0.02)
+    b = T("pb", (1408,), 0.1)
+    pos = T("pos", (1, 257, 1408), 0.1)
+    cls = T("cls", (1, 1, 1408), 0.1)
+    td = torch_dtype(dtype)
+    sd = {"patch_embed.proj.weight": w.to(td).float(), "patch_embed.proj.bias": b, "cls_token": cls, "pos_embed": pos}
+    ref = O.vit_embed(frames.to(td).float(), sd, "")
+    x = torch.empty((n * 257, 1408), device="cuda")
+    hip.gemm(None, pack.patch_weight(w.cuda(), dtype), dtype=dtype, epilogue=hip.EPI_PATCH, bias=b.cuda(), out=x,
+             frames=frames.cuda(), pos_embed=pos.cuda().view(257, 1408), n_frames=n)
+    hip.vit_cls_rows(cls.cuda().view(-1), pos.cuda().view(257, 1408), x, n)
+    check(x.view(n, 257, 1408), ref, ACC_TOL[dtype], "patch embed + cls + pos")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gemm_two_level_rows(hip, dtype):
+    """Q-Former row groups: A rows read from / out rows written into a [N, S, C] buffer."""
+    N_, S, Q, C, Nout = 5, 44, 32, 768, 256
+    buf, buf64 = rnd("buf", (N_ * S, C), dtype)
+    w, w64 = rnd("w", (Nout, C), dtype, 0.05)
+    ref_q = buf64.view(N_, S, C)[:, :Q].reshape(-1, C) @ w64.t()
+    ref_t = buf64.view(N_, S, C)[:, Q:].reshape(-1, C) @ w64.t()
+    out = torch.zeros((N_ * S, Nout), device="cuda", dtype=torch.float32)
+    hip.gemm(buf, w, dtype=dtype, out=out, out_f32=True, M=N_ * Q, a_rows=(Q, S * C), o_rows=(Q, S * Nout))
+    hip.gemm(buf[Q:], w, dtype=dtype, out=out[Q:], out_f32=True, M=N_ * (S - Q), a_rows=(S - Q, S * C),
+             o_rows=(S - Q, S * Nout))
+    o = out.view(N_, S, Nout)
+    check(o[:, :Q].reshape(-1, Nout), ref_q, ACC_TOL[dtype], "query rows")
+    check(o[:, Q:].reshape(-1, Nout), ref_t, ACC_TOL[dtype], "text rows")
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    a = torch.zeros((8, 100), device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple"):
+        hip.gemm(a, w, dtype="bf16")
+    with pytest.raises(RuntimeError):
+        hip.gemm(a.cpu(), w, dtype="bf16")
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("D", [768, 1408, 4096])
+def test_layernorm_rmsnorm(hip, dtype, D):
+    M = 131
+    x = T("x", (M, D), 3.0) + 0.7
+    g = T("g", (D,), 0.2) + 1.0
+    b = T("b", (D,), 0.1)
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6)
+    ot, of = hip.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, dtype=dtype, want_f32=True)
+    check(of, ref, 2e-6, "layernorm f32")
+    check(ot, ref, OUT_TOL[dtype], "layernorm T")
+    ref = O.rms_norm(x.double(), g.double(), 1e-6)
+    ot, of = hip.rmsnorm(x.cuda(), g.cuda(), 1e-6, dtype=dtype, want_f32=True)
+    check(of, ref, 2e-6, "rmsnorm f32")
+    check(ot, ref, OUT_TOL[dtype], "rmsnorm T")
+
+
+def _attn_ref(q, k, v, scale, causal, kv_len):
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    s = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(Sq, Skv).triu(1).bool(), float("-inf"))
+    if kv_len is not None:
+        dead = torch.arange(Skv)[None, :] >= torch.tensor(kv_len)[:, None]
+        s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    return s.softmax(-1) @ v
+
+
+ATTN_CASES = [  # name, B, H, Sq, Skv, D, causal, kv_len
+    ("vit", 3, 16, 257, 257, 88, False, None),
+    ("qf_self", 4, 12, 32, 32, 64, False, None),
+    ("qf_self_text", 3, 12, 44, 44, 64, False, [44, 41, 33]),
+    ("qf_cross", 4, 12, 32, 257, 64, False, None),
+    ("llama_causal", 2, 8, 200, 200, 128, True, None),
+    ("llama_causal_pad", 2, 8, 131, 131, 128, True, [131, 97]),
+    ("llama_short", 1, 4, 7, 7, 128, True, None),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(hip, dtype, case):
+    _, B, H, Sq, Skv, D, causal, kv_len = case
+    # q/k/v as column slices of one fused buffer, exactly how the model calls it
+    C = 3 * H * D
+    if Sq == Skv:
+        buf, buf64 = rnd("qkv", (B * Sq, C), dtype)
+        q, k, v = buf[:, :H * D], buf[:, H * D:2 * H * D], buf[:, 2 * H * D:]
+        q64, k64, v64 = [buf64[:, i * H * D:(i + 1) * H * D].reshape(B, Sq, H, D).transpose(1, 2) for i in range(3)]
+    else:
+        q, q64 = rnd("q", (B * Sq, H * D), dtype)
+        kv, kv64 = rnd("kv", (B * Skv, 2 * H * D), dtype)
+        k, v = kv[:, :H * D], kv[:, H * D:]
+        q64 = q64.view(B, Sq, H, D).transpose(1, 2)
+        k64 = kv64[:, :H * D].reshape(B, Skv, H, D).transpose(1, 2)
+        v64 = kv64[:, H * D:].reshape(B, Skv, H, D).transpose(1, 2)
+    scale = D ** -0.5
+    ref = _attn_ref(q64, k64, v64, scale, causal, kv_len).transpose(1, 2).reshape(B * Sq, H * D)
+    kl = None if kv_len is None else torch.tensor(kv_len, dtype=torch.int32).cuda()
+    out = hip.attention(q, k, v, B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=scale, causal=causal, kv_len=kl)
+    if kv_len is not None and causal:
+        # padded query rows are defined (attend to the valid keys) — compared as well
+        pass
+    # P is rounded to the compute dtype before P.V: allow 2 roundings
+    check(out, ref, 2 * OUT_TOL[dtype] if dtype != "fp32" else 2e-5, f"attention {case[0]}")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_attention_online_softmax_rescale(hip, dtype):
+    """Force the running max to jump late (rule 26): one key far down the sequence dominates."""
+    B, H, S, D = 1, 2, 160, 128
+    q, q64 = rnd("q", (S, H * D), dtype, 0.3)
+    k, k64 = rnd("k", (S, H * D), dtype, 0.3)
+    v, v64 = rnd("v", (S, H * D), dtype)
+    k[150] = (q[5] * 6).to(k.dtype)
+    k64[150] = k[150].double().cpu()
+    r = lambda t: t.view(1, S, H, D).transpose(1, 2)
+    ref = _attn_ref(r(q64), r(k64), r(v64), D ** -0.5, False, None).transpose(1, 2).reshape(S, H * D)
+    out = hip.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5)
+    check(out, ref, 2 * OUT_TOL[dtype], "late-max rescale")
+
+
+# ---------------------------------------------------------------------------------------------
+def test_gather_mean_cls_cosine_ce(hip):
+    D = 4096
+    a = T("ga", (50, D))
+    b = T("gb", (70, D))
+    add = T("gadd", (9, D))
+    idx = torch.tensor([3, -1, 49, -70, 0, 7, -5], dtype=torch.int32)
+    ia = torch.tensor([0, 8, 3, 3, 1, 2, 5], dtype=torch.int32)
+    ref = torch.stack([a[i] if i >= 0 else b[-i - 1] for i in idx.tolist()])
+    out = hip.gather_rows(a.cuda(), idx.cuda(), src_b=b.cuda())
+    assert torch.equal(out.cpu(), ref)
+    out = hip.gather_rows(a.cuda(), idx.cuda(), src_b=b.cuda(), add=add.cuda(), idx_add=ia.cuda())
+    assert torch.equal(out.cpu(), ref + add[ia.long()])
+    x = T("mx", (2, 8, 32, D))
+    check(hip.mean_t(x.cuda()), x.double().mean(1), 1e-6, "mean_t")
+    u, w = T("cu", (40, D)), T("cw", (64, D))
+    iu = torch.arange(40, dtype=torch.int32)
+    iw = torch.randperm(64, generator=torch.Generator().manual_seed(0))[:40].to(torch.int32)
+    ref = 2 - 2 * (F.normalize(u.double(), dim=-1) * F.normalize(w.double()[iw.long()], dim=-1)).sum(-1)
+    check(hip.cosine_rows(u.cuda(), w.cuda(), iu.cuda(), iw.cuda()), ref, 1e-5, "cosine rows")
+    V = 32000
+    lg = T("lg", (33, V), 2.0)
+    lab = torch.randint(0, V, (33,), generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    lab[5] = -100
+    ref = F.cross_entropy(lg.double(), lab.long(), ignore_index=-100, reduction="none")
+    check(hip.cross_entropy_rows(lg.cuda(), lab.cuda()), ref, 1e-5, "cross entropy rows")

@@ -1,0 +1,84 @@
+"""CPU: the oracle (oracle/stllm_oracle.py) against the golden vectors captured from the
+reference's own model code (tests/golden/make_fixtures.py).  fp32 both sides; tolerance 2e-5
+relative to the tensor's abs-max (summation order differs between the reference's torch graph and
+the restatement only in a few places, e.g. the explicit im2col GEMM)."""
+import numpy as np
+import pytest
+import torch
+
+import shapes
+import stllm_oracle as O
+from _util import T, golden, sd_from, stats, sub, unragged, assert_close
+
+torch.set_grad_enabled(False)
+RTOL = 2e-5
+
+
+def close(got, want, what):
+    want = np.asarray(want)
+    assert_close(got, want, atol=RTOL * max(1.0, float(np.abs(want).max())), what=what)
+
+
+def test_vit_ops():
+    g = golden("vit_ops")
+    sd = sd_from({**shapes.vit_shapes(2), "ln_vision.weight": (1408,), "ln_vision.bias": (1408,)})
+    frames = T("input.frames", (2, 3, 224, 224))
+    h0 = T("input.h0", (2, 257, 1408))
+    p = "visual_encoder."
+    pe = O.vit_patch_embed(frames, sd, p)
+    close(sub(pe, 1, 5, 7), g["patch_embed"], "patch_embed")
+    close(stats(pe), g["patch_embed_stats"], "patch_embed stats")
+    close(sub(O.vit_attention(h0, sd, p + "blocks.0.attn."), 1, 4, 9), g["attn"], "attention")
+    close(sub(O.vit_mlp(h0, sd, p + "blocks.0.mlp."), 1, 4, 9), g["mlp"], "mlp")
+    close(sub(O.vit_block(h0, sd, p + "blocks.0."), 1, 4, 9), g["block"], "block")
+    feat = O.vit_forward(frames, sd, p)
+    close(sub(feat, 1, 4, 9), g["feat"], "forward_features")
+    close(stats(feat), g["feat_stats"], "forward_features stats")
+    close(sub(O.ln_vision(feat, sd, "ln_vision"), 1, 4, 9), g["ln_vision"], "ln_vision")
+
+
+def test_qformer():
+    g = golden("qformer")
+    sd = sd_from({**shapes.qformer_shapes(12, True, 30523), "query_tokens": (1, 32, 768)})
+    enc = T("input.image_embeds", (2, 257, 1408))
+    q = sd["query_tokens"].expand(2, -1, -1)
+    ids = torch.from_numpy(g["input_ids"])
+    tmask = torch.from_numpy(g["text_mask"])
+    att = torch.cat([torch.ones(2, 32, dtype=torch.long), tmask], dim=1)
+    o_text = O.qformer_forward(q, enc, sd, "Qformer.bert.", ids, att)
+    close(sub(o_text, 1, 1, 3), g["out_text"], "qformer with text")
+    close(stats(o_text), g["out_text_stats"], "qformer with text stats")
+    o_plain = O.qformer_forward(q, enc, sd, "Qformer.bert.")
+    close(sub(o_plain, 1, 1, 3), g["out_plain"], "qformer without text")
+    # stripped (MiniGPT4) == full without text: same oracle call on a state dict without text params
+    sd2 = {k: v for k, v in sd.items() if k in shapes.qformer_shapes(12, False) or k == "query_tokens"}
+    assert torch.equal(O.qformer_forward(q, enc, sd2, "Qformer.bert."), o_plain)
+    h = T("input.qf_h", (2, 44, 768))
+    add = (1.0 - att[:, None, None, :].float()) * -10000.0
+    close(sub(O.bert_layer(h, add, enc, 0, sd, "Qformer.bert.", 32), 1, 1, 3), g["layer0"], "even BertLayer")
+    close(sub(O.bert_layer(h, add, enc, 1, sd, "Qformer.bert.", 32), 1, 1, 3), g["layer1"], "odd BertLayer")
+
+
+def test_pooling_and_masking():
+    g = golden("pooling")
+    sd = sd_from({"down_proj.weight": (1024, 4096), "down_proj.bias": (1024,),
+                  "up_proj.weight": (4096, 1024), "up_proj.bias": (4096,)})
+    emb = T("input.inputs_llama", (2, 8, 32, 4096), 0.5)
+    res = O.video_pool(emb, "residual", sd, "", 4)
+    close(sub(res, 1, 1, 1, 32), g["residual"], "residual pooling")
+    close(stats(res), g["residual_stats"], "residual pooling stats")
+    close(sub(O.video_pool(emb, "mean", sd), 1, 1, 1, 32), g["mean"], "mean pooling")
+    assert O.video_pool(emb, "all", sd).shape == (2, 1, 256, 4096)
+    for k in g.files:
+        if k.startswith("idx_"):
+            r, t = map(int, k.split("_")[1:])
+            assert np.array_equal(O.get_residual_index(r, t), g[k]), k
+    # masking: same numpy RNG stream as the reference => identical mask; then the gather
+    np.random.seed(7)
+    mask = O.random_masking_generator(256, 0.37, 2)
+    assert np.array_equal(mask, g["mask"])
+    kept = O.apply_mask(emb.reshape(2, 1, -1, 4096), torch.from_numpy(mask))
+    assert kept.shape == (2, 1, 256 - int(0.37 * 256), 4096)
+    close(sub(kept, 1, 1, 1, 64), g["kept"], "masked gather")
+    # inference twin (Chat.upload_video): [T,32,D] -> [1,L,D]
+    close(sub(O.video_pool_infer(emb[0], "residual", sd, "", 4), 1, 1, 32), g["residual"][0], "infer residual")
