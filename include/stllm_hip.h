@@ -155,6 +155,10 @@ int stllm_cosine_rows(const float* a, int64_t lda, const int32_t* idx_a, const f
 int stllm_cross_entropy_rows(const float* logits, int64_t ldl, const int32_t* labels, float* loss,
                              int n_rows, int V, void* stream);
 
+/* out T[M,D] = cast(x f32[M,D]) — the .to(dtype)/type_as casts at st_llm.py:453,474 and the autocast
+ * boundary of blip2.py:36-44, when a GEMM consumes rows of the fp32 stream without a norm in between. */
+int stllm_cast_rows(int dtype, const float* x, int64_t ldx, void* out, int64_t ldo, int M, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""Tensor path of the reference's Chat wrapper (stllm/conversation/conversation.py:181-340): what
+``demo.py`` drives — ``upload_video`` -> ``encode_img`` -> pooling -> prompt-embedding concat ->
+``generate(inputs_embeds=...)``.  Video decoding, PIL transforms, prompt templates and stopping criteria are
+host-side text/media utilities and out of scope."""
+import torch
+
+from . import hip, runtime
+from .models.st_llm import get_residual_index
+
+
+class Chat:
+    def __init__(self, model, device="cuda:0"):
+        self.device = device
+        self.LLM = model
+        # conversation.py:185-190 — the visual front-end hangs off model.model (or model.model.model under peft)
+        self.model = model.model.stllm_model if hasattr(model.model, "stllm_model") else model.model.model.stllm_model
+
+    def upload_video(self, video, conv, img_list, num_frame=64, text=None):
+        """conversation.py:274-299 with `video` already a frames tensor ([T*3,224,224] or [T,3,224,224], CLIP-normalised)."""
+        frames = video.to(self.device)
+        if frames.dim() == 3:
+            bt, w, h = frames.shape
+            frames = frames.view(bt // 3, 3, w, h)
+        m = self.model
+        video_emb, _, _ = m.encode_img(frames, text=text)  # [T,32,4096]
+        if m.video_input == "mean":
+            video_emb = hip.mean_t(video_emb.unsqueeze(0).contiguous())
+        elif m.video_input == "all":
+            video_emb = video_emb.reshape(1, -1, video_emb.shape[-1])
+        elif m.video_input == "residual":
+            video_emb = m.pool_video(video_emb.unsqueeze(0))[:, 0]
+        img_list.append(video_emb)
+        if conv is not None:
+            conv.append_message(conv.roles[0], "<Video><ImageHere></Video>")
+        return "Received."
+
+    def get_context_emb_ids(self, img_list, question_ids):
+        """conversation.py:322-340 (get_context_emb_sim) on token ids: cat(video_emb, embed([BOS]+question))."""
+        tk = self.model.llama_tokenizer
+        ids = [[tk.bos_token_id] + list(question_ids)]
+        seg = self.model.embed_tokens(torch.tensor(ids))
+        mixed = torch.cat((img_list[0], seg), dim=1)
+        att = torch.ones(mixed.shape[:-1], dtype=torch.long, device=mixed.device)
+        return mixed, att
+
+    def get_context_emb_sim(self, conv, img_list, system=True):
+        question = conv.messages[0][1].split("</Video> ")[1]
+        question = (conv.system if system else "") + "###Human: " + question + " ###Assistant: "
+        return self.get_context_emb_ids(img_list, self.model.llama_tokenizer.encode_ids(question, add_special_tokens=False))
+
+    def answer(self, img_list, question_ids, max_new_tokens=300, max_length=2000, **kw):
+        """conversation.py:213-253: keep the last `max_length` embeddings, then generate."""
+        embs, att = self.get_context_emb_ids(img_list, question_ids)
+        begin = max(0, embs.shape[1] - (max_length - max_new_tokens))
+        embs = embs[:, begin:]
+        out = self.LLM.generate(inputs_embeds=embs, max_new_tokens=max_new_tokens, **kw)
+        return self.model.llama_tokenizer.decode(out[0].tolist()), out[0].cpu().numpy()

@@ -92,6 +92,25 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) loss[row] = logf(red[0] + red[1] + red[2] + red[3]) + mx - x[lab];
 }
 
+// fp32 -> compute dtype rows (A operand of a GEMM whose input lives in the fp32 residual stream)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ x, int64_t ldx, void* __restrict__ out,
+                                                        int64_t ldo, int D) {
+  const int row = blockIdx.x;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+  for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) {
+    const float4 v = xr[c];
+    if constexpr (Elem<T>::kIsF32) {
+      reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo)[c] = v;
+    } else {
+      uint2 pk;
+      pk.x = (uint32_t)Elem<T>::pack(v.x) | ((uint32_t)Elem<T>::pack(v.y) << 16);
+      pk.y = (uint32_t)Elem<T>::pack(v.z) | ((uint32_t)Elem<T>::pack(v.w) << 16);
+      reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + (int64_t)row * ldo)[c] = pk;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int stllm_gather_rows(const float* src_a, int64_t ld_a, const float* src_b, int64_t ld_b,
@@ -143,5 +162,20 @@ extern "C" int stllm_cross_entropy_rows(const float* logits, int64_t ldl, const 
   hipLaunchKernelGGL(ce_rows_kernel, dim3(n_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ldl,
                      labels, loss, V);
   STLLM_CHECK_LAUNCH("stllm_cross_entropy_rows");
+  return STLLM_OK;
+}
+
+extern "C" int stllm_cast_rows(int dtype, const float* x, int64_t ldx, void* out, int64_t ldo, int M, int D,
+                               void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  STLLM_CHECK_ARG(x && out && M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "stllm_cast_rows: bad args");
+  STLLM_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "stllm_cast_rows: misaligned");
+  switch (dtype) {
+    case STLLM_BF16: hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(M), dim3(256), 0, stream, x, ldx, out, ldo, D); break;
+    case STLLM_F16: hipLaunchKernelGGL(cast_rows_kernel<f16_t>, dim3(M), dim3(256), 0, stream, x, ldx, out, ldo, D); break;
+    case STLLM_F32: hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(M), dim3(256), 0, stream, x, ldx, out, ldo, D); break;
+    default: stllm_set_error("stllm_cast_rows: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;
+  }
+  STLLM_CHECK_LAUNCH("stllm_cast_rows");
   return STLLM_OK;
 }

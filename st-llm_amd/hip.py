@@ -21,7 +21,7 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows"]
+           "stllm_cross_entropy_rows", "stllm_cast_rows"]
 
 
 def torch_dtype(d):
@@ -71,6 +71,7 @@ def lib():
         L.stllm_cosine_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
                                         c_int, c_void_p]
         L.stllm_cross_entropy_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]
+        L.stllm_cast_rows.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]
         for n in EXPORTS[2:]:
             getattr(L, n).restype = c_int
         _lib = L
@@ -246,4 +247,16 @@ def cross_entropy_rows(logits, labels):
     out = torch.empty((n,), device=logits.device, dtype=torch.float32)
     _check(lib().stllm_cross_entropy_rows(_p(logits), logits.stride(0), _p(labels), _p(out), n, V, _stream()),
            "stllm_cross_entropy_rows")
+    return out
+
+
+def cast_rows(x, dtype, out=None):
+    """x f32 [M,D] (row-strided ok) -> compute dtype [M,D]."""
+    _req(x, torch.float32, "x")
+    td = torch_dtype(dtype)
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), device=x.device, dtype=td)
+    _check(lib().stllm_cast_rows(dtype_code(td), _p(x), x.stride(0), _p(out), out.stride(0), M, D, _stream()),
+           "stllm_cast_rows")
     return out

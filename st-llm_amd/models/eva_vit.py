@@ -1,0 +1,158 @@
+"""EVA-CLIP-g ViT behind the reference's surface (stllm/models/eva_vit.py), running on the HIP C ABI.
+
+Module / parameter names follow the reference (eva_vit.py:76-82,115,157-165,196,263-265) so its
+checkpoints load unchanged.  Per block (eva_vit.py:173-180, gamma_1/2 None for eva_clip_g):
+
+    LN(eps 1e-6) -> [QKV GEMM + (q_bias,0,v_bias)] -> fused attention (16 heads x 88, scale 88^-0.5 folded
+    into the softmax) -> [proj GEMM + bias + fp32 residual] -> LN -> [fc1 GEMM + bias + exact-erf GELU]
+    -> [fc2 GEMM + bias + fp32 residual]
+
+The residual stream is fp32; GEMM/attention operands are the compute dtype (runtime.compute_dtype()).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import hip, pack, runtime
+from .layers import LayerNorm, Linear, _dev
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, device=None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = Linear(dim, dim * 3, bias=False, device=device)
+        self.q_bias = nn.Parameter(torch.empty(dim, device=_dev(device)), requires_grad=False)
+        self.v_bias = nn.Parameter(torch.empty(dim, device=_dev(device)), requires_grad=False)
+        self.proj = Linear(dim, dim, device=device)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden, device=None):
+        super().__init__()
+        self.fc1 = Linear(dim, hidden, device=device)
+        self.fc2 = Linear(hidden, dim, device=device)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.3637, eps=1e-6, device=None):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, eps, device)
+        self.attn = Attention(dim, num_heads, device)
+        self.norm2 = LayerNorm(dim, eps, device)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), device)
+
+    def pack(self, dtype):
+        a, m = self.attn, self.mlp
+        return dict(n1w=self.norm1.weight, n1b=self.norm1.bias, e1=self.norm1.eps,
+                    wqkv=pack.linear(a.qkv.weight, dtype), bqkv=pack.vit_qkv_bias(a.q_bias, a.v_bias),
+                    wproj=pack.linear(a.proj.weight, dtype), bproj=pack.f32(a.proj.bias),
+                    n2w=self.norm2.weight, n2b=self.norm2.bias, e2=self.norm2.eps,
+                    wfc1=pack.linear(m.fc1.weight, dtype), bfc1=pack.f32(m.fc1.bias),
+                    wfc2=pack.linear(m.fc2.weight, dtype), bfc2=pack.f32(m.fc2.bias))
+
+
+def block_forward(x, pk, n_seq, seq_len, num_heads, dt):
+    """One pre-LN transformer block on the flat fp32 stream x [n_seq*seq_len, dim], in place."""
+    dim = x.shape[1]
+    hd = dim // num_heads
+    h, _ = hip.layernorm(x, pk["n1w"], pk["n1b"], pk["e1"], dtype=dt)
+    qkv = hip.gemm(h, pk["wqkv"], dtype=dt, bias=pk["bqkv"])
+    a = hip.attention(qkv[:, :dim], qkv[:, dim:2 * dim], qkv[:, 2 * dim:], B=n_seq, H=num_heads, Sq=seq_len,
+                      Skv=seq_len, D=hd, scale=hd ** -0.5)
+    hip.gemm(a, pk["wproj"], dtype=dt, epilogue=hip.EPI_RESID, bias=pk["bproj"], resid=x)
+    h, _ = hip.layernorm(x, pk["n2w"], pk["n2b"], pk["e2"], dtype=dt)
+    g = hip.gemm(h, pk["wfc1"], dtype=dt, bias=pk["bfc1"], act=hip.ACT_GELU)
+    hip.gemm(g, pk["wfc2"], dtype=dt, epilogue=hip.EPI_RESID, bias=pk["bfc2"], resid=x)
+    return x
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=14, in_chans=3, embed_dim=1408, device=None):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.patch_shape = (img_size // patch_size, img_size // patch_size)
+        self.proj = nn.Module()
+        self.proj.weight = nn.Parameter(torch.empty(embed_dim, in_chans, patch_size, patch_size, device=_dev(device)),
+                                        requires_grad=False)
+        self.proj.bias = nn.Parameter(torch.empty(embed_dim, device=_dev(device)), requires_grad=False)
+
+
+class VisionTransformer(nn.Module):
+    """eva_vit.VisionTransformer (eva_vit.py:246-370) for the eva_clip_g configuration only
+    (img 224, patch 14, dim 1408, 16 heads, abs pos-embed, no rel-pos bias, no LayerScale, no final norm)."""
+
+    def __init__(self, img_size=224, patch_size=14, embed_dim=1408, depth=39, num_heads=16, mlp_ratio=4.3637,
+                 eps=1e-6, device=None, **unused):
+        super().__init__()
+        if img_size != 224 or patch_size != 14 or embed_dim != 1408:
+            raise NotImplementedError("HIP patch-embed kernel is specialised for EVA-CLIP-g (224/14/1408)")
+        self.image_size = img_size
+        self.num_features = self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.patch_embed = PatchEmbed(img_size, patch_size, 3, embed_dim, device)
+        self.cls_token = nn.Parameter(torch.empty(1, 1, embed_dim, device=_dev(device)), requires_grad=False)
+        self.pos_embed = nn.Parameter(torch.empty(1, self.patch_embed.num_patches + 1, embed_dim, device=_dev(device)),
+                                      requires_grad=False)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, eps, device) for _ in range(depth)])
+        self._packed = {}
+
+    # -- packing ---------------------------------------------------------------------------------
+    def pack(self, dtype=None):
+        dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
+        if dt not in self._packed:
+            self._packed = {dt: dict(
+                wpatch=pack.patch_weight(self.patch_embed.proj.weight, dt), bpatch=pack.f32(self.patch_embed.proj.bias),
+                pos=self.pos_embed.detach().view(-1, self.embed_dim).float().contiguous(),
+                cls=self.cls_token.detach().view(-1).float().contiguous(),
+                blocks=[b.pack(dt) for b in self.blocks])}
+        return self._packed[dt]
+
+    def repack(self):
+        self._packed = {}
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    # -- forward ---------------------------------------------------------------------------------
+    def embed_flat(self, x, pk, dt):
+        """patch-embed implicit GEMM + CLS + pos_embed -> flat fp32 stream [N*257, 1408]"""
+        N, C, H, W = x.shape
+        assert H == self.patch_embed.img_size[0] and W == self.patch_embed.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.patch_embed.img_size[0]}*{self.patch_embed.img_size[1]})."
+        x = x.float().contiguous()
+        out = torch.empty((N * 257, self.embed_dim), device=x.device, dtype=torch.float32)
+        hip.gemm(None, pk["wpatch"], dtype=dt, epilogue=hip.EPI_PATCH, bias=pk["bpatch"], out=out, frames=x,
+                 pos_embed=pk["pos"], n_frames=N)
+        hip.vit_cls_rows(pk["cls"], pk["pos"], out, N)
+        return out
+
+    def forward_features_flat(self, x):
+        dt = runtime.compute_dtype()
+        pk = self.pack(dt)
+        N = x.shape[0]
+        h = self.embed_flat(x, pk, dt)
+        for bp in pk["blocks"]:
+            block_forward(h, bp, N, 257, self.num_heads, dt)
+        return h
+
+    def forward_features(self, x):
+        return self.forward_features_flat(x).view(x.shape[0], 257, self.embed_dim)
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+
+def create_eva_vit_g(img_size=224, drop_path_rate=0.4, use_checkpoint=False, precision="fp16", depth=39, device=None):
+    """eva_vit.create_eva_vit_g (eva_vit.py:415-443) without the checkpoint download (no network): random
+    parameters are left uninitialised for the caller to fill (synth / load_state_dict)."""
+    return VisionTransformer(img_size=img_size, patch_size=14, embed_dim=1408, depth=depth, num_heads=1408 // 88,
+                             mlp_ratio=4.3637, eps=1e-6, device=device)

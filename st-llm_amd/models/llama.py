@@ -1,0 +1,162 @@
+"""Vicuna-7B / Llama-1 decoder PREFILL on the HIP C ABI, HF parameter names.
+
+The reference imports HF ``transformers.models.llama`` (st_llm.py:20; pinned 4.28.0) — third-party code
+that is not in the reference tree; its in-tree statement is stllm/models/modeling_llama_mem.py:61-144.
+Per layer:
+
+    RMSNorm -> [fused QKV GEMM + rotate-half RoPE epilogue] -> causal flash attention (+ right-pad mask)
+    -> [o_proj GEMM + fp32 residual] -> RMSNorm -> [gate/up GEMM + SiLU(gate)*up epilogue]
+    -> [down_proj GEMM + fp32 residual]
+
+then the final RMSNorm and lm_head on ALL positions (st_llm.py:122).  The decode loop with a KV cache is
+out of scope this round: ``generate`` below re-runs the prefill per new token.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip, pack, runtime
+from .layers import Embedding, Linear, Output, RMSNorm
+
+
+class LlamaConfig:
+    model_type = "llama"
+
+    def __init__(self, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                 vocab_size=32000, rms_norm_eps=1e-6, max_position_embeddings=2048, rope_theta=10000.0, **kw):
+        self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.vocab_size, self.rms_norm_eps = vocab_size, rms_norm_eps
+        self.max_position_embeddings, self.rope_theta = max_position_embeddings, rope_theta
+        self.__dict__.update(kw)
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg, device):
+        super().__init__()
+        d = cfg.hidden_size
+        self.q_proj = Linear(d, d, bias=False, device=device)
+        self.k_proj = Linear(d, d, bias=False, device=device)
+        self.v_proj = Linear(d, d, bias=False, device=device)
+        self.o_proj = Linear(d, d, bias=False, device=device)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, cfg, device):
+        super().__init__()
+        self.gate_proj = Linear(cfg.hidden_size, cfg.intermediate_size, bias=False, device=device)
+        self.up_proj = Linear(cfg.hidden_size, cfg.intermediate_size, bias=False, device=device)
+        self.down_proj = Linear(cfg.intermediate_size, cfg.hidden_size, bias=False, device=device)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg, device):
+        super().__init__()
+        self.self_attn = LlamaAttention(cfg, device)
+        self.mlp = LlamaMLP(cfg, device)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
+
+    def pack(self, dt, n_heads):
+        a, m = self.self_attn, self.mlp
+        return dict(ln1=self.input_layernorm.weight, ln2=self.post_attention_layernorm.weight,
+                    wqkv=pack.llama_qkv(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dt, n_heads),
+                    wo=pack.linear(a.o_proj.weight, dt),
+                    wgu=pack.llama_gate_up(m.gate_proj.weight, m.up_proj.weight, dt),
+                    wdown=pack.linear(m.down_proj.weight, dt))
+
+
+class LlamaModel(nn.Module):
+    def __init__(self, config, device=None):
+        super().__init__()
+        self.config = config
+        if config.hidden_size // config.num_attention_heads != 128:
+            raise NotImplementedError("RoPE epilogue / attention kernels are specialised for head_dim 128")
+        self.embed_tokens = Embedding(config.vocab_size, config.hidden_size, device)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, device) for _ in range(config.num_hidden_layers)])
+        self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps, device)
+        self._packed = {}
+        self._rope = {}
+
+    def pack(self, dtype=None):
+        dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
+        if dt not in self._packed:
+            self._packed = {}  # one packed copy at a time (13.5 GB at 7B)
+            self._packed[dt] = [l.pack(dt, self.config.num_attention_heads) for l in self.layers]
+        return self._packed[dt]
+
+    def repack(self):
+        self._packed = {}
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    def rope(self, S, device):
+        if S not in self._rope:
+            d = self.config.hidden_size // self.config.num_attention_heads
+            self._rope = {S: pack.rope_tables(S, d, self.config.rope_theta, device)}
+        return self._rope[S]
+
+    def prefill(self, inputs_embeds, attention_mask=None):
+        """inputs_embeds f32 [B,S,D]; attention_mask [B,S] (1 = token, right-padded) or None.
+        Returns (hidden f32 [B,S,D] after model.norm == hidden_states[-1], hidden in compute dtype [B*S,D])."""
+        cfg = self.config
+        dt = runtime.compute_dtype()
+        layers = self.pack(dt)
+        B, S, D = inputs_embeds.shape
+        H = cfg.num_attention_heads
+        hd = D // H
+        dev = inputs_embeds.device
+        x = inputs_embeds.reshape(B * S, D).float().clone()
+        kv_len = None
+        if attention_mask is not None:
+            m = attention_mask.to("cpu").long()
+            if not bool((m[:, 1:] <= m[:, :-1]).all()):
+                raise NotImplementedError("only right-padded attention masks occur on this path (st_llm.py:400-404)")
+            if int(m.sum()) != m.numel():
+                kv_len = m.sum(dim=1).to(torch.int32).to(dev)
+        cos, sin = self.rope(S, dev)
+        for pk in layers:
+            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
+            qkv = hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D)
+            a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, D=hd,
+                              scale=hd ** -0.5, causal=True, kv_len=kv_len)
+            hip.gemm(a, pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+            h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
+            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+        h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
+        return h32.view(B, S, D), h16
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, use_cache=False,
+                output_hidden_states=False, return_dict=True, **kw):
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        hidden, h16 = self.prefill(inputs_embeds, attention_mask)
+        out = Output(last_hidden_state=hidden, past_key_values=None,
+                     hidden_states=(hidden,) if output_hidden_states else None, attentions=None)
+        out._h16 = h16
+        return out
+
+
+class LlamaForCausalLM(nn.Module):
+    def __init__(self, config, device=None):
+        super().__init__()
+        self.config = config
+        self.model = LlamaModel(config, device)
+        self.vocab_size = config.vocab_size
+        self.lm_head = Linear(config.hidden_size, config.vocab_size, bias=False, device=device)
+        self._lm_packed = {}
+
+    def lm_weight(self, dt):
+        ver = (self.lm_head.weight._version, self.lm_head.weight.data_ptr())
+        hit = self._lm_packed.get(dt)
+        if hit is None or hit[0] != ver:
+            hit = (ver, pack.pad_rows(pack.linear(self.lm_head.weight, dt), 128))
+            self._lm_packed = {dt: hit}
+        return hit[1]
+
+    def logits_from(self, h16, B, S):
+        dt = runtime.compute_dtype()
+        lg = hip.gemm(h16, self.lm_weight(dt), dtype=dt, out_f32=True)
+        return lg.view(B, S, -1)[..., : self.vocab_size]

@@ -82,3 +82,93 @@ def test_pooling_and_masking():
     close(sub(kept, 1, 1, 1, 64), g["kept"], "masked gather")
     # inference twin (Chat.upload_video): [T,32,D] -> [1,L,D]
     close(sub(O.video_pool_infer(emb[0], "residual", sd, "", 4), 1, 1, 32), g["residual"][0], "infer residual")
+
+
+def test_llama_prefill():
+    g = golden("llama")
+    sd = sd_from(shapes.llama_shapes(2))
+    x = T("input.inputs_embeds", (2, 45, 4096), 0.05)
+    am = torch.from_numpy(g["attention_mask"])
+    h1 = O.llama_forward(x, am, {k: v for k, v in sd.items() if "layers.1." not in k}, final_norm=False)
+    close(sub(h1, 1, 1, 16), g["layer0"], "llama layer 0")
+    hid = O.llama_forward(x, am, sd)
+    close(sub(hid, 1, 1, 16), g["hidden"], "llama hidden")
+    close(stats(hid), g["hidden_stats"], "llama hidden stats")
+    lg = O.lm_logits(hid, sd)
+    close(sub(lg, 1, 1, 61), g["logits"], "logits")
+    close(stats(lg), g["logits_stats"], "logits stats")
+
+
+def test_btadapter():
+    g = golden("btadapter")
+    sd = sd_from(shapes.btadapter_shapes(5, 3))
+    x5 = T("input.video", (2, 4, 3, 224, 224))
+    o5, br = O.btadapter_forward(x5, sd, "visual_encoder.", 3, return_branches=True)
+    close(sub(o5, 1, 4, 9), g["out5"], "btadapter 5-D")
+    close(stats(o5), g["out5_stats"], "btadapter 5-D stats")
+    for j, b in enumerate(br):
+        close(sub(b, 1, 16, 9), g[f"branch{j}"], f"branch {j}")
+    o4 = O.btadapter_forward(x5[0], sd, "visual_encoder.", 3)
+    close(sub(o4, 1, 4, 9), g["out4"], "btadapter 4-D")
+
+
+def _e2e(name, cfg, Tn, text):
+    g = golden(name)
+    sdshape = {**shapes.stllm_model_shapes(2, 2, text, cfg["video_input"], cfg.get("mvm_decode", False), qf_vocab=32000),
+               **shapes.llama_shapes(2)}
+    sd = sd_from(sdshape)
+    samples = {"image": T("input.video", (2, Tn, 3, 224, 224)), "before_ids": unragged(g["before"]),
+               "after_ids": unragged(g["after"]), "answer_ids": unragged(g["answer"])}
+    if text:
+        # the reference's BERT tokenizer call uses add_special_tokens=True (st_llm.py:344): the fixture's
+        # FakeTokenizer prepends its BOS id (1)
+        qt = [[1] + r for r in unragged(g["qtext"])]
+        L = max(len(r) for r in qt)
+        ids = torch.zeros(2, L, dtype=torch.long)
+        m = torch.zeros(2, L, dtype=torch.long)
+        for i, r in enumerate(qt):
+            ids[i, :len(r)] = torch.tensor(r)
+            m[i, :len(r)] = 1
+        samples["qformer_ids"], samples["qformer_mask"] = ids, m
+    if cfg.get("use_mask"):
+        samples["mask"] = torch.from_numpy(g["mask"])
+    out = O.stllm_forward(samples, sd, dict(cfg, pad_id=0, bos_id=1))
+    assert np.array_equal(out["attention_mask"].numpy(), g["attention_mask"])
+    assert np.array_equal(out["targets"].numpy(), g["targets"])
+    close(sub(out["inputs_embeds"], 1, 1, 16), g["inputs_embeds"], "inputs_embeds")
+    close(stats(out["inputs_embeds"]), g["inputs_embeds_stats"], "inputs_embeds stats")
+    close(sub(out["hidden"], 1, 1, 16), g["hidden"], "hidden")
+    close(sub(out["logits"], 1, 1, 61), g["logits"], "logits")
+    close(stats(out["logits"]), g["logits_stats"], "logits stats")
+    assert abs(out["loss"].item() - g["loss"][0]) < 2e-4 * max(1.0, abs(g["loss"][0]))
+    if g["loss"][1] >= 0:
+        assert abs(out["loss_mvm"].item() - g["loss"][1]) < 2e-5
+
+
+CFG_MINIGPT4 = dict(vit_model="eva_clip_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False)
+CFG_INSTRUCTBLIP = dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
+                        qformer_text_input=True)
+
+
+def test_stllm_minigpt4_style():
+    _e2e("stllm_minigpt4", CFG_MINIGPT4, 4, False)
+
+
+def test_stllm_instructblip_style():
+    _e2e("stllm_instructblip", CFG_INSTRUCTBLIP, 8, True)
+
+
+def test_chat_upload_video_path():
+    g = golden("chat")
+    sd = sd_from({**shapes.stllm_model_shapes(2, 2, True, "residual", False, qf_vocab=32000), **shapes.llama_shapes(2)})
+    p = "model.stllm_model."
+    frames = T("input.frames4", (4, 3, 224, 224))
+    qt = torch.tensor([1] + g["qtext"].tolist()).view(1, -1).repeat(4, 1)
+    emb = O.encode_img(frames, sd, p, "eva_clip_g", qt, torch.ones_like(qt))
+    vemb = O.video_pool_infer(emb, "residual", sd, p, 2)
+    close(sub(vemb, 1, 1, 16), g["video_emb"], "video_emb")
+    qids = torch.tensor([[1] + g["question"].tolist()])
+    mixed = torch.cat((vemb, sd["model.embed_tokens.weight"][qids]), dim=1)
+    lg = O.lm_logits(O.llama_forward(mixed, None, sd), sd)
+    close(sub(lg, 1, 1, 61), g["logits"], "prefill logits")
+    close(lg[0, -1].numpy()[::7], g["last_logits"], "first-step logits")
