@@ -53,6 +53,8 @@ typedef enum { STLLM_ACT_NONE = 0, STLLM_ACT_GELU = 1, STLLM_ACT_RELU = 2 } stll
 
 const char* stllm_last_error(void);
 int stllm_abi_version(void);
+/* name of the kernel template instantiation chosen by the last stllm_gemm call on this thread (for profiling) */
+const char* stllm_last_kernel(void);
 
 /*
  * C[M,N] = epilogue(A[M,K] @ W[N,K]^T)  on MFMA, LDS-tiled (128-byte K panels, XOR-swizzled).

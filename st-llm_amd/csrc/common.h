@@ -11,6 +11,7 @@
 // host: error plumbing
 // ---------------------------------------------------------------------------------------------
 void stllm_set_error(const char* fmt, ...);
+void stllm_set_last_kernel(const char* name);  // static-lifetime string: symbol family of the last launch
 
 #define STLLM_CHECK_ARG(cond, ...)                 \
   do {                                             \
@@ -84,6 +85,7 @@ template <> struct Elem<f16_t> {
 template <> struct Elem<float> {
   static constexpr int kBytes = 4;
   static constexpr bool kIsF32 = true;
+  __device__ static __forceinline__ uint16_t pack(float) { return 0; }  // never used: fp32 outputs are stored as-is
   // One 16-byte fragment = 4 consecutive k of this lane's half; the k <-> (step, half) slot map is
   // the same for A and B, so 4 exact-fp32 MFMAs (K=2 each) consume one fragment pair.
   __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {

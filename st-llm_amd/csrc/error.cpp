@@ -15,3 +15,7 @@ void stllm_set_error(const char* fmt, ...) {
 
 extern "C" const char* stllm_last_error(void) { return g_err; }
 extern "C" int stllm_abi_version(void) { return 1; }
+
+static thread_local const char* g_last_kernel = "";
+void stllm_set_last_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* stllm_last_kernel(void) { return g_last_kernel; }

@@ -19,7 +19,7 @@ _DT = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
 _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
           "bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}
 
-EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
+EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
            "stllm_cross_entropy_rows", "stllm_cast_rows"]
 
@@ -57,6 +57,7 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.stllm_last_error.restype = c_char_p
         L.stllm_abi_version.restype = c_int
+        L.stllm_last_kernel.restype = c_char_p
         L.stllm_gemm.argtypes = [ctypes.POINTER(GemmArgs), c_void_p]
         L.stllm_layernorm.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int, c_int, c_void_p]
@@ -72,7 +73,7 @@ def lib():
                                         c_int, c_void_p]
         L.stllm_cross_entropy_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]
         L.stllm_cast_rows.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]
-        for n in EXPORTS[2:]:
+        for n in EXPORTS[3:]:
             getattr(L, n).restype = c_int
         _lib = L
     return _lib
@@ -99,6 +100,31 @@ def _req(t, dtype=None, what="tensor"):
     if t.dim() >= 1 and t.stride(-1) != 1:
         raise RuntimeError(f"{what}: last dim must be contiguous")
     return t
+
+
+class GemmProfiler:
+    """HIP-event timing of GEMM launches on the launch stream (bench.py roofline leg).
+    mode 'all': time every launch (calibration); mode 'target': only launches whose kernel symbol == target."""
+
+    def __init__(self):
+        self.mode, self.target = "all", None
+        self.sym_of = {}      # (dtype, epilogue, M, N, K) -> kernel symbol, learned in 'all' mode
+        self.records = {}     # symbol -> [(start_evt, end_evt, algorithmic_flops)]
+
+    def summary(self):
+        out = {}
+        for sym, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[sym] = dict(launches=len(recs), total_ms=ms, flops=sum(f for _, _, f in recs))
+        return out
+
+
+_profiler = None
+
+
+def set_profiler(p):
+    global _profiler
+    _profiler = p
 
 
 # ----------------------------------------------------------------------------------------------
@@ -150,7 +176,19 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         args.o_rows_per_batch, args.o_batch_stride = o_rows
     args.out, args.ldo = _p(out), out.stride(-2)
     args.M, args.N, args.K = M, N, K
+    prof, start = _profiler, None
+    if prof is not None:
+        key = (args.dtype, epilogue, M, N, K)
+        if prof.mode == "all" or prof.sym_of.get(key) == prof.target:
+            start = torch.cuda.Event(enable_timing=True)
+            start.record()
     _check(lib().stllm_gemm(ctypes.byref(args), _stream()), "stllm_gemm")
+    if start is not None:
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        sym = lib().stllm_last_kernel().decode()
+        prof.sym_of[key] = sym
+        prof.records.setdefault(sym, []).append((start, end, 2.0 * M * N * K))
     return out
 
 

@@ -92,6 +92,13 @@ class STLLMModel(Blip2Base):
         self.llama_proj = Linear(self.Qformer.config.hidden_size, 4096, device=device)
         self.max_txt_len, self.end_sym = max_txt_len, end_sym
         self.embed_tokens = None  # set by STLLMLlamaModel.initialize_vision_modules (st_llm.py:54)
+        self.frame_parallel = None  # (rank, world, group): see stllm_amd.parallel
+
+    def set_frame_parallel(self, rank, world, group=None):
+        """Shard the per-frame encode over `world` GPUs (one all-gather of visual tokens) and the prefill by clip."""
+        if world > 1 and self.vit_model != "eva_clip_g":
+            raise NotImplementedError("BT-Adapter couples the frames of a clip (temporal attention): shard by clip instead")
+        self.frame_parallel = (rank, world, group) if world > 1 else None
 
     # ------------------------------------------------------------------------------------------
     def _qformer_ids(self, text, n_frames, T):
@@ -110,6 +117,23 @@ class STLLMModel(Blip2Base):
         T = image.shape[1]
         infer = image.dim() == 4
         use_image = True if T == 1 or infer else False
+        if self.frame_parallel is not None and not infer:
+            from .. import parallel
+            rank, world, group = self.frame_parallel
+            frames = image.reshape((-1,) + tuple(image.shape[2:]))
+            qtext = text
+
+            def enc_local(fr, _s=[0]):
+                s0, _ = parallel.frame_range(frames.shape[0], rank, world)
+                t_local = None
+                if self.qformer_text_input:  # each rank needs the text of the clips its frames belong to
+                    all_t = [qtext] * frames.shape[0] if isinstance(qtext, str) else [t for t in qtext for _ in range(T)]
+                    t_local = all_t[s0: s0 + fr.shape[0]]
+                return self._encode_frames(fr, t_local, T, dt)
+            tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group)
+            inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
+            atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
+            return inputs_llama, atts_llama, use_image
         if self.vit_model == "eva_clip_g":
             frames = image.reshape((-1,) + tuple(image.shape[2:])) if image.dim() == 5 else image
             feats = self.visual_encoder.forward_features_flat(frames)
@@ -128,6 +152,19 @@ class STLLMModel(Blip2Base):
             inputs_llama = inputs_llama.view(-1, T, inputs_llama.shape[1], 4096)
         atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
         return inputs_llama, atts_llama, use_image
+
+    def _encode_frames(self, frames, text_per_frame, T, dt):
+        """ViT -> ln_vision -> Q-Former -> projector for a flat list of frames -> [n,32,4096] fp32."""
+        n = frames.shape[0]
+        feats = self.visual_encoder.forward_features_flat(frames)
+        enc16, _ = hip.layernorm(feats, self.ln_vision.weight, self.ln_vision.bias, self.ln_vision.eps, dtype=dt)
+        ids = tmask = None
+        if self.qformer_text_input:
+            tok = self.tokenizer(text_per_frame, padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
+            ids, tmask = tok.input_ids, tok.attention_mask
+        _, hq16, _ = self.Qformer.bert.encode(self.query_tokens[0], enc16, n, ids, tmask)
+        w, b = self.llama_proj.packed(dt)
+        return hip.gemm(hq16, w, dtype=dt, bias=b, out_f32=True).view(n, -1, 4096)
 
     # ------------------------------------------------------------------------------------------
     def pool_video(self, img_embeds):
@@ -221,6 +258,21 @@ class STLLMModel(Blip2Base):
             img_embeds = self.pool_video(img_embeds)
         elif img_embeds.dim() == 3:
             img_embeds = img_embeds.unsqueeze(1)
+        answers_txt = list(samples["answer"])
+        if self.frame_parallel is not None and not use_image:
+            # clip-parallel prefill: this rank continues with the clips it owns (clip c -> rank c % world)
+            from .. import parallel
+            rank, world, _ = self.frame_parallel
+            own = parallel.clips_of_rank(img_embeds.shape[0], rank, world)
+            self.owned_clips = own
+            if not own:
+                return None
+            img_embeds = img_embeds[own].contiguous()
+            if instruction is not None and not isinstance(instruction, str):
+                instruction = [instruction[c] for c in own]
+            answers_txt = [answers_txt[c] for c in own]
+            if "mask" in samples and samples["mask"] is not None:
+                samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
         B, _, L, D = img_embeds.shape
         dev = img_embeds.device
         kept = [list(range(L)) for _ in range(B)]
@@ -237,8 +289,8 @@ class STLLMModel(Blip2Base):
             self.mask_img_len = len(kept[0])
             assert all(len(k) == self.mask_img_len for k in kept)
         self.llama_tokenizer.padding_side = "right"
-        text = [t + self.llama_tokenizer.eos_token for t in samples["answer"]] if self.qformer_text_input \
-            else [t + self.end_sym for t in samples["answer"]]
+        text = [t + self.llama_tokenizer.eos_token for t in answers_txt] if self.qformer_text_input \
+            else [t + self.end_sym for t in answers_txt]
         tr = self.llama_tokenizer(text, return_tensors="pt", padding="longest", truncation=True,
                                   max_length=self.max_txt_len, add_special_tokens=False)
         answers = [tr.input_ids[b][: int(tr.attention_mask[b].sum())].tolist() for b in range(B)]
@@ -286,7 +338,10 @@ class STLLMLlamaModel(LlamaModel):
         if samples is None:
             return super().forward(inputs_embeds=inputs_embeds, **kwargs)
         sm = self.stllm_model
-        inputs_embeds, attention_mask, un_e, un_a, labels = sm(samples)
+        res = sm(samples)
+        if res is None:  # frame-parallel run and this rank owns no clip of the batch
+            return None, None, None
+        inputs_embeds, attention_mask, un_e, un_a, labels = res
         outputs = super().forward(attention_mask=attention_mask, inputs_embeds=inputs_embeds, use_cache=False,
                                   output_hidden_states=un_e is not None, return_dict=True)
         if un_e is None:
@@ -341,6 +396,8 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
             return Output(loss=None, logits=self.logits_from(out._h16, B, S), past_key_values=None,
                           hidden_states=out.hidden_states, attentions=None)
         outputs, loss_pretrain, labels = self.model(samples)
+        if outputs is None:
+            return Output(loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None)
         B, S, _ = outputs.last_hidden_state.shape
         logits = self.logits_from(outputs._h16, B, S)
         loss = None

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GEMM shapes on the hot path (config 2: T=16, S=576).  GPU only.
+    python tools/gemm_bench.py [--dtype bf16] [--iters 20] [--only name,...]
+Random [-1,1)-ish operands (never zero-filled: guide rule 25)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from stllm_amd import hip, pack  # noqa: E402
+
+SHAPES = [  # name, M, N, K, epilogue, launches per clip
+    ("vit_qkv", 4112, 4224, 1408, "store", 39), ("vit_proj", 4112, 1408, 1408, "resid", 39),
+    ("vit_fc1", 4112, 6144, 1408, "gelu", 39), ("vit_fc2", 4112, 1408, 6144, "resid", 39),
+    ("qf_ckv", 4112, 1536, 1408, "store", 6), ("qf_qkv", 512, 2304, 768, "store", 12),
+    ("qf_ffn1", 512, 3072, 768, "gelu", 12), ("qf_ffn2", 512, 768, 3072, "resid", 12),
+    ("llm_qkv", 576, 12288, 4096, "rope", 32), ("llm_o", 576, 4096, 4096, "resid", 32),
+    ("llm_gu", 576, 22016, 4096, "swiglu", 32), ("llm_down", 576, 4096, 11008, "resid", 32),
+    ("lm_head", 576, 32000, 4096, "store32", 1)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    td = hip.torch_dtype(a.dtype)
+    only = set(a.only.split(",")) if a.only else None
+    total_ms = 0.0
+    total_fl = 0.0
+    for name, M, N, K, epi, per_clip in SHAPES:
+        if only and name not in only:
+            continue
+        A = (torch.rand(M, K, device="cuda") * 2 - 1).to(td)
+        W = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(td)
+        bias = torch.rand(N, device="cuda")
+        x = torch.rand(M, N, device="cuda")
+        cos, sin = pack.rope_tables(576, device="cuda")
+        kw = dict(dtype=td)
+        if epi == "store": kw.update(bias=bias)
+        elif epi == "store32": kw.update(out_f32=True)
+        elif epi == "gelu": kw.update(bias=bias, act=hip.ACT_GELU)
+        elif epi == "resid": kw.update(bias=bias, epilogue=hip.EPI_RESID, resid=x)
+        elif epi == "swiglu": kw.update(epilogue=hip.EPI_SWIGLU)
+        elif epi == "rope": kw.update(epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=576, rope_cols=8192)
+        out = None if epi == "resid" else hip.gemm(A, W, **kw)
+        if out is not None: kw["out"] = out
+        for _ in range(3): hip.gemm(A, W, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.iters): hip.gemm(A, W, **kw)
+        e.record(); torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / a.iters
+        fl = 2.0 * M * N * K
+        total_ms += ms * per_clip; total_fl += fl * per_clip
+        print(f"{name:9s} M={M:5d} N={N:6d} K={K:6d} {epi:8s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF   x{per_clip:2d} = {ms * per_clip:6.3f} ms  [{hip.lib().stllm_last_kernel().decode()}]")
+    print(f"total GEMM time per clip: {total_ms:.3f} ms  ({total_fl / total_ms / 1e9:.1f} TF/s average)")
+
+
+if __name__ == "__main__":
+    main()

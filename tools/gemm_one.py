@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc passes).  python tools/gemm_one.py M N K [iters] [epi]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stllm_amd import hip
+M, N, K = map(int, sys.argv[1:4])
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+epi = sys.argv[5] if len(sys.argv) > 5 else "store"
+A = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
+W = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(torch.bfloat16)
+x = torch.rand(M, N, device="cuda")
+for _ in range(iters):
+    if epi == "resid":
+        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_RESID, resid=x)
+    else:
+        hip.gemm(A, W, dtype="bf16")
+torch.cuda.synchronize()
+print("done", hip.lib().stllm_last_kernel().decode())
