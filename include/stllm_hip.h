@@ -133,13 +133,14 @@ int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q_rs,
 
 /*
  * Row gather (token-block assembly, dynamic masking, residual-index selection, embedding lookup):
- *   dst[i, :] = (idx_a[i] >= 0 ? src_a[idx_a[i], :] : src_b[-idx_a[i]-1, :]) + (add ? add[idx_add[i], :] : 0)
- * all f32, D % 4 == 0.  Replaces torch.cat / index / embed_tokens glue at st_llm.py:391-404,
+ *   dst[i, :] = scale * ((idx_a[i] >= 0 ? src_a[idx_a[i], :] : src_b[-idx_a[i]-1, :]) + (add ? add[idx_add[i], :] : 0))
+ * all f32, D % 4 == 0.  The same kernel re-orders tokens between the BT-Adapter's spatial '(b t) p' and temporal
+ * 'b (p t)' layouts and averages branches (eva_btadapter.py:179-196, 261-310).  Replaces torch.cat / index / embed_tokens glue at st_llm.py:391-404,
  * 416-431, 473-476, 491, 509, 524-530 and conversation.py:288-293, 336-337.
  */
 int stllm_gather_rows(const float* src_a, int64_t ld_a, const float* src_b, int64_t ld_b,
                       const int32_t* idx_a, const float* add, int64_t ld_add, const int32_t* idx_add,
-                      float* dst, int64_t ld_dst, int n_rows, int D, void* stream);
+                      float* dst, int64_t ld_dst, int n_rows, int D, float scale, void* stream);
 
 /* out[b, j] = mean_t x[b, t, j]  (x f32 [B,T,J] contiguous) — st_llm.py:468,471; conversation.py:282,287 */
 int stllm_mean_t(const float* x, float* out, int B, int T, int64_t J, void* stream);

@@ -246,7 +246,7 @@ template <typename T>
 int dispatch(const AttnParams& p, hipStream_t stream) {
   // NW picked so that 32*NW divides the common sequence lengths with little waste:
   //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
-  if (p.D == 88) return launch_mfma<T, 96, 3>(p, stream);
+  if (p.D == 88) return p.Sq <= 32 ? launch_mfma<T, 96, 1>(p, stream) : launch_mfma<T, 96, 3>(p, stream);  // Sq<=32: BT-Adapter temporal attention
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
   if (p.D == 128) return launch_mfma<T, 128, 3>(p, stream);
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);

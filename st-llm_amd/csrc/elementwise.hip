@@ -9,7 +9,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
                                                           const int32_t* __restrict__ idx_a,
                                                           const float* __restrict__ add, int64_t ld_add,
                                                           const int32_t* __restrict__ idx_add,
-                                                          float* __restrict__ dst, int64_t ld_dst, int n_rows, int D) {
+                                                          float* __restrict__ dst, int64_t ld_dst, int n_rows, int D,
+                                                          float scale) {
   const int row = blockIdx.x;
   if (row >= n_rows) return;
   const int ia = idx_a[row];
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   for (int c = threadIdx.x; c < (D >> 2); c += blockDim.x) {
     float4 v = s[c];
     if (a) { const float4 w = a[c]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    if (scale != 1.0f) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
     d[c] = v;
   }
 }
@@ -115,14 +117,14 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 
 extern "C" int stllm_gather_rows(const float* src_a, int64_t ld_a, const float* src_b, int64_t ld_b,
                                  const int32_t* idx_a, const float* add, int64_t ld_add, const int32_t* idx_add,
-                                 float* dst, int64_t ld_dst, int n_rows, int D, void* stream) {
+                                 float* dst, int64_t ld_dst, int n_rows, int D, float scale, void* stream) {
   STLLM_CHECK_ARG(src_a && idx_a && dst, "stllm_gather_rows: null pointer");
   STLLM_CHECK_ARG(n_rows > 0 && D > 0 && D % 4 == 0, "stllm_gather_rows: bad n_rows=%d D=%d", n_rows, D);
   STLLM_CHECK_ARG(ld_a % 4 == 0 && ld_dst % 4 == 0 && aligned16(src_a) && aligned16(dst), "stllm_gather_rows: misaligned");
   STLLM_CHECK_ARG(!src_b || (ld_b % 4 == 0 && aligned16(src_b)), "stllm_gather_rows: src_b misaligned");
   STLLM_CHECK_ARG(!add || (idx_add && ld_add % 4 == 0 && aligned16(add)), "stllm_gather_rows: add needs idx_add, aligned");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(n_rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_a, ld_a,
-                     src_b, ld_b, idx_a, add, ld_add, idx_add, dst, ld_dst, n_rows, D);
+                     src_b, ld_b, idx_a, add, ld_add, idx_add, dst, ld_dst, n_rows, D, scale);
   STLLM_CHECK_LAUNCH("stllm_gather_rows");
   return STLLM_OK;
 }

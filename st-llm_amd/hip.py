@@ -66,7 +66,7 @@ def lib():
         L.stllm_attention.argtypes = [c_int] + [c_void_p, c_int64, c_int64] * 4 + [c_int] * 5 + [c_float, c_int,
                                                                                               c_void_p, c_void_p]
         L.stllm_gather_rows.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                        c_void_p, c_int64, c_int, c_int, c_void_p]
+                                        c_void_p, c_int64, c_int, c_int, c_float, c_void_p]
         L.stllm_mean_t.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]
         L.stllm_vit_cls_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]
         L.stllm_cosine_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
@@ -242,15 +242,15 @@ def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, ou
     return out
 
 
-def gather_rows(src_a, idx_a, *, src_b=None, add=None, idx_add=None, out=None):
-    """out[i] = (idx_a[i] >= 0 ? src_a[idx_a[i]] : src_b[-idx_a[i]-1]) (+ add[idx_add[i]])."""
+def gather_rows(src_a, idx_a, *, src_b=None, add=None, idx_add=None, out=None, scale=1.0):
+    """out[i] = scale * ((idx_a[i] >= 0 ? src_a[idx_a[i]] : src_b[-idx_a[i]-1]) (+ add[idx_add[i]]))."""
     _req(src_a, torch.float32, "src_a"); _req(idx_a, torch.int32, "idx_a")
     n, D = idx_a.numel(), src_a.shape[-1]
     if out is None:
         out = torch.empty((n, D), device=src_a.device, dtype=torch.float32)
     _check(lib().stllm_gather_rows(_p(src_a), src_a.stride(0), _p(src_b), src_b.stride(0) if src_b is not None else 0,
                                    _p(idx_a), _p(add), add.stride(0) if add is not None else 0, _p(idx_add),
-                                   _p(out), out.stride(0), n, D, _stream()), "stllm_gather_rows")
+                                   _p(out), out.stride(0), n, D, scale, _stream()), "stllm_gather_rows")
     return out
 
 

@@ -176,3 +176,89 @@ def test_chat_upload_video_and_prefill(mode, tol):
         ids = model.generate(inputs_embeds=embs, max_new_tokens=2)
         assert ids.shape == (1, 2)
         assert int(ids[0, 0]) == int(out.logits[0, -1].argmax())
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
+def test_btadapter_backbone(mode, tol):
+    """A11 / config 5: EVA ViT + BT-Adapter (5-block ViT, adapter depth 3, NON-zero temporal_fc), 5-D and 4-D input."""
+    from stllm_amd import runtime
+    from stllm_amd.models.eva_btadapter import create_eva_btadapter
+    g = golden("btadapter")
+    m = fill(create_eva_btadapter(depth=5, adapter_depth=3, device="cuda"), "visual_encoder.")
+    x5 = T("input.video", (2, 4, 3, 224, 224)).cuda()
+    with runtime.use_dtype(mode):
+        o5 = m(x5)
+        o4 = m(x5[0])
+    assert o5.shape == (8, 257, 1408) and o4.shape == (4, 257, 1408)
+    assert rel_err(sub(o5, 1, 4, 9), g["out5"]) <= tol, "BT-Adapter 5-D vs golden"
+    assert rel_err(sub(o4, 1, 4, 9), g["out4"]) <= tol, "BT-Adapter 4-D vs golden"
+    assert rel_err(stats(o5)[:2], g["out5_stats"][:2]) <= tol
+
+
+def test_config5_minigpt4base_btadapter_vs_oracle():
+    """BASELINE config 5 shape (minigpt4base_stllm_qa.yaml: BT-Adapter backbone, video_input all, mask + MVM, no text
+    Q-Former, BOS prepended, img_start 8) at reduced depth, product vs oracle in verify mode."""
+    from stllm_amd import runtime, synth
+    from stllm_amd.models import st_llm
+    from stllm_amd.models.blip2 import Blip2Base
+    cfg = dict(vit_model="eva_btadapter_g", image_size=224, num_query_token=32, video_input="all", use_mask=True,
+               mvm_decode=True, qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    old = (Blip2Base.vit_depth, Blip2Base.qformer_layers)
+    Blip2Base.vit_depth, Blip2Base.qformer_layers = 4, 2
+    try:
+        model = st_llm.STLLMForCausalLM.from_config(dict(cfg, llama_model=dict(num_hidden_layers=1)), device="cuda")
+    finally:
+        Blip2Base.vit_depth, Blip2Base.qformer_layers = old
+    fill(model)
+    B, Tn = 2, 4
+    g = torch.Generator().manual_seed(3)
+    ids = lambda n: torch.randint(3, 32000, (n,), generator=g).tolist()
+    before, after, answer = [ids(7) for _ in range(B)], [ids(4 + i) for i in range(B)], [ids(5 + i) for i in range(B)]
+    s = lambda r: " ".join(map(str, r))
+    image = T("input.video", (B, Tn, 3, 224, 224))
+    np.random.seed(11)
+    mask = torch.from_numpy(O.random_masking_generator(Tn * 32, 0.5, B))
+    samples = {"image": image.cuda(), "instruction_input": [f"{s(before[i])}<ImageHere>{s(after[i])}" for i in range(B)],
+               "answer": [s(a) for a in answer], "mask": mask}
+    sd = sd_from({**shapes.stllm_model_shapes(4, 2, False, "all", True, vit_model="eva_btadapter_g"), **shapes.llama_shapes(1)})
+    ref = O.stllm_forward({"image": image, "before_ids": before, "after_ids": after, "answer_ids": [a + [2] for a in answer],
+                           "mask": mask}, sd, dict(cfg, pad_id=0, bos_id=1))
+    with runtime.use_dtype("fp32"):
+        out = model(samples=samples)
+    err = float((out.logits.cpu() - ref["logits"]).abs().max())
+    print(f"\n[config5 fp32] logits max-abs err {err:.3e}; loss {out.loss.item():.5f} vs {ref['loss'].item():.5f}")
+    assert err <= 1e-2
+    assert abs(out.loss.item() - ref["loss"].item()) <= 1e-3
+
+
+def test_config3_global_local_t64_vs_oracle():
+    """BASELINE config 3 shape: B=2 clips x T=64 frames, global-local module R=16 (residual), text Q-Former — pooling and
+    token-block assembly at full T (ViT depth 1 so that it runs in seconds), verify mode vs oracle."""
+    from stllm_amd import runtime
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="residual", residual_size=16,
+               use_mask=False, mvm_decode=False, qformer_text_input=True, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=1, qf_layers=1, llm_layers=1)
+    B, Tn = 2, 64
+    g = torch.Generator().manual_seed(4)
+    ids = lambda n: torch.randint(3, 30000, (n,), generator=g).tolist()
+    before, after, answer, qtext = [ids(3)] * B, [ids(4), ids(6)], [ids(5), ids(3)], [ids(6), ids(4)]
+    s = lambda r: " ".join(map(str, r))
+    image = T("input.video64", (B, Tn, 3, 224, 224))
+    samples = {"image": image.cuda(), "answer": [s(a) for a in answer],
+               "instruction_input": [f"{s(before[i])}<ImageHere>{s(after[i])} Human: {s(qtext[i])} ###" for i in range(B)]}
+    sd = sd_from({**shapes.stllm_model_shapes(1, 1, True, "residual", False, qf_vocab=32000), **shapes.llama_shapes(1)})
+    L = max(len(q) + 1 for q in qtext)
+    qi, qm = torch.zeros(B, L, dtype=torch.long), torch.zeros(B, L, dtype=torch.long)
+    for i, q in enumerate(qtext):
+        qi[i, :len(q) + 1] = torch.tensor([1] + q)
+        qm[i, :len(q) + 1] = 1
+    ref = O.stllm_forward({"image": image, "before_ids": before, "after_ids": [[1] + after[i] + qtext[i] for i in range(B)],
+                           "answer_ids": [a + [2] for a in answer], "qformer_ids": qi, "qformer_mask": qm}, sd,
+                          dict(cfg, pad_id=0, bos_id=1))
+    with runtime.use_dtype("fp32"):
+        out = model(samples=samples)
+    assert out.logits.shape == ref["logits"].shape
+    valid = ref["attention_mask"].bool()
+    err = float((out.logits.cpu() - ref["logits"])[valid].abs().max())
+    print(f"\n[config3-shape fp32] S={out.logits.shape[1]} logits max-abs err {err:.3e}")
+    assert err <= 1e-2
