@@ -14,6 +14,7 @@
 //   * block -> tile map is XCD-aware (block b runs on XCD b % 8): each XCD gets a contiguous run of
 //     tiles that share operand panels in its private L2.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -33,6 +34,7 @@ struct GemmParams {
   int M, N, K;                     // K in elements (padded)
   int act, out_is_f32;
   int tiles_m, tiles_n;
+  char* ws; int64_t ws_bytes; int epoch;   // stream-K workspace: [4 KiB flags | per-workgroup fp32 slabs], launch epoch
   int debug;                       // ablation bits (env STLLM_GEMM_DEBUG): 1 skip staging, 2 skip MFMA loop, 4 skip copy-out
   int a_rpb; int64_t a_bs_b;       // A 2-level rows: rows per batch, batch stride (bytes)
   int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
@@ -89,6 +91,8 @@ __device__ __forceinline__ i32x4 patch_chunk(const float* __restrict__ frames, i
   }
   return r;
 }
+
+static int g_debug_early() { static int d = -1; if (d < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); d = e ? atoi(e) : 0; } return d; }
 
 constexpr int kGroupM = 8;  // tile rows per L2 locality group
 
@@ -436,7 +440,18 @@ int launch(const GemmParams& p0, hipStream_t stream) {
   }
   // persistent grid: every workgroup is resident (LDS-limited workgroups per CU x 256 CUs)
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int grid = ntiles < Tile<BM, BN>::kMaxPersistent ? ntiles : Tile<BM, BN>::kMaxPersistent;
+  static int max_wg = 0;
+  if (max_wg == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_kernel<T, BM, BN, EPI, ACT, OF32>, kThreads, lds);
+    if (per_cu < 1) per_cu = 1;
+    max_wg = per_cu * prop.multiProcessorCount;
+    if (g_debug_early() & 8) fprintf(stderr, "[stllm] gemm<%d,%d> occupancy %d WG/CU x %d CUs\n", BM, BN, per_cu, prop.multiProcessorCount);
+  }
+  const int grid = ntiles < max_wg ? ntiles : max_wg;
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, ACT, OF32>), dim3(grid), dim3(kThreads), lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_gemm");
   {
@@ -453,8 +468,408 @@ int launch(const GemmParams& p0, hipStream_t stream) {
   return STLLM_OK;
 }
 
+
+// =====================================================================================================
+// Stream-K variant: 512 threads = 8 waves as 2(M) x 4(N), tile BM x 256, one workgroup per CU.
+//
+// Why (profiles/r01_gemm_ablation.md): with a 128x128 tile the HBM/L2 -> LDS panel stream takes as long as the
+// MFMA loop (64 FLOP per LDS-filled byte).  A BM x 256 tile raises that to 85 (BM=128) / 128 (BM=256) FLOP/B and
+// the 3-stage (BM=128) ring keeps two panels in flight.  Tiles this large quantise badly on 256 CUs for this
+// workload (M = 4112 or 576, N = 1408 ... 32000), so the flattened (tile, K-panel) space is cut into G equal
+// ranges (stream-K): a workgroup may start and end in the middle of a tile.
+//   * a range that starts inside a tile produces a PARTIAL: raw fp32 accumulators -> its slab in the workspace,
+//     then an agent-scope release + flag (the workgroup does this first, so partials are ready early);
+//   * the workgroup that owns panel 0 of a tile FINALISES it: after its own panels it polls the flags of the
+//     contributors (relaxed, one lane, bounded spin), one agent-scope acquire, adds their slabs in workgroup
+//     order (deterministic) and runs the fused epilogue.
+// Finalisers only ever wait for higher-numbered workgroups doing their FIRST segment; all G <= 256 workgroups
+// are resident (one per CU: 128-144 KiB LDS each), so the protocol is placement- and order-independent.
+// Flags carry the launch epoch (host counter), so no memset is needed between launches on one stream.
+// =====================================================================================================
+constexpr int kSkFlagBytes = 4096;
+constexpr int kSkMaxSlabWG = 512;
+
+// tile configurations: 128x128 (4 waves, 2 stages, 2 workgroups/CU), 128x256 (8 waves, 3 stages), 256x256 (8 waves, 2 stages)
+template <int BM, int BN> struct SkTile {
+  static constexpr int NWN = BN / 64, NWAVES = 2 * NWN, NT = 64 * NWAVES;
+  static constexpr int MI = BM / 64, NI = 2;
+  static constexpr int kStageBytes = (BM + BN) * kRowBytes;
+  static constexpr int NS = (BM + BN == 384) ? 3 : 2;
+  static constexpr int kLdsBytes = NS * kStageBytes;
+  static constexpr int kPPW = (BM + BN) / 8 / NWAVES;       // LDS-DMA pieces per wave per panel
+  static constexpr int kMaxWG = (160 * 1024 / kLdsBytes) * 256;
+  static constexpr int64_t kSlabBytes = (int64_t)BM * BN * 4;
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int EPI, int ACT, bool OF32>
+__global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) {
+  using TL = SkTile<BM, BN>;
+  constexpr int NT = TL::NT, NWAVES = TL::NWAVES, NWN = TL::NWN;
+  constexpr int MI = TL::MI, NI = TL::NI, NS = TL::NS, PPW = TL::kPPW;
+  constexpr int EB = Elem<T>::kBytes;
+  constexpr int kElemsPerPanel = kRowBytes / EB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#define STLLM_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int nk = p.K / kElemsPerPanel;
+  const int64_t total = (int64_t)ntiles * nk;
+  const int G = gridDim.x;
+  const int g = xcd_remap(blockIdx.x, G);
+  auto range_start = [&](int gg) -> int64_t { return total * gg / G; };
+  const int64_t u_begin = range_start(g), u_end = range_start(g + 1);
+  const int n_units = (int)(u_end - u_begin);
+  if (n_units <= 0) return;
+
+  unsigned* flags = reinterpret_cast<unsigned*>(p.ws);
+  float* slabs = reinterpret_cast<float*>(p.ws + kSkFlagBytes);
+
+  // ---- staging plan (per tile): combined tile rows [0,BM) = A, [BM,BM+BN) = W; wave w owns pieces w, w+NWAVES, ...
+  const char* gsrc[PPW];
+  auto a_row = [&](int gr) -> const char* {
+    gr = gr < p.M ? gr : p.M - 1;
+    int64_t off = (int64_t)gr * p.lda_b;
+    if (p.a_rpb > 0) { const int bb = gr / p.a_rpb; off = (int64_t)bb * p.a_bs_b + (int64_t)(gr - bb * p.a_rpb) * p.lda_b; }
+    return p.A + off;
+  };
+  auto plan = [&](int tile) {
+    int tm, tn;
+    tile_coords(tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave + NWAVES * j;
+      const int r = piece * 8 + (lane >> 3);
+      const int c = lane & 7;
+      const int lc = c ^ ((r >> 1) & 7);
+      if (r < BM) {
+        gsrc[j] = a_row(m0 + r) + lc * 16;
+      } else {
+        int gr = n0 + (r - BM); gr = gr < p.N ? gr : p.N - 1;
+        gsrc[j] = p.W + (int64_t)gr * p.ldw_b + lc * 16;
+      }
+    }
+  };
+  auto stage = [&](int k, int buf) {
+    char* dst = smem + buf * TL::kStageBytes;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) glds16(gsrc[j] + (int64_t)k * kRowBytes, dst + (wave + NWAVES * j) * 1024);
+  };
+
+  // ---- load cursor (runs NS-1 panels ahead of the compute cursor) ------------------------------------------
+  int l_left = n_units;                 // panels not yet issued
+  int l_tile = (int)(u_begin / nk), l_k = (int)(u_begin - (int64_t)l_tile * nk);
+  int l_cnt = 0;
+  plan(l_tile);
+  auto issue = [&]() {
+    if (l_left <= 0) return;
+    stage(l_k, l_cnt % NS);
+    ++l_cnt; --l_left; ++l_k;
+    if (l_k == nk) { l_k = 0; ++l_tile; if (l_left > 0) plan(l_tile); }
+  };
+#pragma unroll
+  for (int q = 0; q < NS - 1; ++q) issue();
+
+  // ---- fragment read offsets ------------------------------------------------------------------------------
+  const int sw = (li >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = ((kk * 2 + lh) ^ sw) << 4;
+  const int a_row_off = (wm * (BM / 2) + li) * kRowBytes;
+  const int b_row_off = (BM + wn * 64 + li) * kRowBytes;
+
+  auto out_off = [&](int row) -> int64_t {
+    if (p.o_rpb > 0) { const int bb = row / p.o_rpb; return (int64_t)bb * p.o_bs + (int64_t)(row - bb * p.o_rpb) * p.ldo; }
+    return (int64_t)row * p.ldo;
+  };
+
+  int c_tile = (int)(u_begin / nk), c_k = (int)(u_begin - (int64_t)c_tile * nk);
+  int seg_k0 = c_k;
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  for (int it = 0; it < n_units; ++it) {
+    const int cur = it % NS;
+    // panel `it` landed; up to NS-2 younger panels may stay in flight across the barrier
+    if (NS == 3 && it + 1 < n_units) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+    STLLM_BAR();
+    issue();  // into the stage consumed in the previous iteration
+    const char* base = smem + cur * TL::kStageBytes;
+    if (!(p.debug & 2)) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        i32x4 af[MI], bf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          af[i] = *reinterpret_cast<const i32x4*>(base + a_row_off + i * 32 * kRowBytes + koff[kk]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          bf[j] = *reinterpret_cast<const i32x4*>(base + b_row_off + j * 32 * kRowBytes + koff[kk]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = Elem<T>::mfma(af[i], bf[j], acc[i][j]);
+      }
+    }
+    ++c_k;
+    if (c_k < nk && it + 1 < n_units) continue;
+
+    // =================== segment [seg_k0, c_k) of tile c_tile finished ===================================
+    int tm, tn;
+    tile_coords(c_tile, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool contrib = seg_k0 > 0;                  // tile was started by a lower-numbered workgroup
+    int ncontrib = 0;                                   // partials this workgroup must add (it owns panel 0)
+    if (!contrib && c_k < nk) {
+      const int64_t tile_end = (int64_t)(c_tile + 1) * nk;
+      while (g + 1 + ncontrib < G && range_start(g + 1 + ncontrib) < tile_end) ++ncontrib;
+      if (wave == 0) {  // one wave polls, relaxed; bounded so that a broken run ends instead of hanging the GPU
+        for (int q = 0; q < ncontrib; ++q) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&flags[g + 1 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.epoch &&
+                 ++spins < (1u << 22))
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    char* ep = smem + cur * TL::kStageBytes;           // the stage just consumed; the others hold future panels
+    constexpr bool kOutT = (EPI == STLLM_EPI_SWIGLU || EPI == STLLM_EPI_ROPE);
+    constexpr bool f32out = (EPI == STLLM_EPI_RESID) || (!kOutT && (OF32 || Elem<T>::kIsF32));
+    constexpr int pitch = BN * 4;
+    float* my_slab = slabs + (int64_t)g * BM * BN;
+
+    for (int pass = 0; pass < 2 * MI; ++pass) {
+      const int pwm = pass / MI, pi = pass - pwm * MI;
+      STLLM_BAR();  // `ep` free (last MFMA reads / previous pass copy-out done); also orders the acquire above
+      if (wm == pwm) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (i != pi) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              *reinterpret_cast<float*>(ep + lrow * pitch + (wn * 64 + j * 32 + li) * 4) = acc[i][j][r];
+          }
+        }
+      }
+      STLLM_BAR();
+      if (p.debug & 4) continue;
+      const int trow0 = pwm * (BM / 2) + pi * 32;       // first tile row of this pass
+      auto ldf4 = [&](int lrow, int col) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ep + lrow * pitch + col * 4);
+        for (int q = 0; q < ncontrib; ++q)
+          v += *reinterpret_cast<const f32x4*>(slabs + (int64_t)(g + 1 + q) * BM * BN + (int64_t)(trow0 + lrow) * BN + col);
+        return v;
+      };
+      auto gf4 = [&](const float* ptr) { return *reinterpret_cast<const f32x4*>(ptr); };
+      auto pack4 = [&](f32x4 a, f32x4 b) {
+        i32x4 o;
+        o[0] = (int)((uint32_t)Elem<T>::pack(a[0]) | ((uint32_t)Elem<T>::pack(a[1]) << 16));
+        o[1] = (int)((uint32_t)Elem<T>::pack(a[2]) | ((uint32_t)Elem<T>::pack(a[3]) << 16));
+        o[2] = (int)((uint32_t)Elem<T>::pack(b[0]) | ((uint32_t)Elem<T>::pack(b[1]) << 16));
+        o[3] = (int)((uint32_t)Elem<T>::pack(b[2]) | ((uint32_t)Elem<T>::pack(b[3]) << 16));
+        return o;
+      };
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      if (contrib) {
+        // raw fp32 partial -> this workgroup's slab (whole 32 x 256 pass, unmasked: the slab is private scratch)
+        for (int c = tid; c < 32 * (BN / 4); c += NT) {
+          const int lrow = c / (BN / 4), cc = (c - lrow * (BN / 4)) * 4;
+          *reinterpret_cast<f32x4*>(my_slab + (int64_t)(trow0 + lrow) * BN + cc) =
+              *reinterpret_cast<const f32x4*>(ep + lrow * pitch + cc * 4);
+        }
+      } else if constexpr (EPI == STLLM_EPI_SWIGLU) {
+        constexpr int IPR = BN / 16;
+        for (int c = tid; c < 32 * IPR; c += NT) {
+          const int lrow = c / IPR, q = c - lrow * IPR;
+          const int row = m0 + trow0 + lrow;
+          const int gq = q >> 2, within = (q & 3) * 8;
+          const int gc = gq * 64 + within, uc = gc + 32;
+          if (row >= p.M || n0 + gc >= p.N) continue;
+          f32x4 ga = ldf4(lrow, gc), gb = ldf4(lrow, gc + 4), ua = ldf4(lrow, uc), ub = ldf4(lrow, uc + 4);
+          if (p.bias) { ga += gf4(p.bias + n0 + gc); gb += gf4(p.bias + n0 + gc + 4); ua += gf4(p.bias + n0 + uc); ub += gf4(p.bias + n0 + uc + 4); }
+          f32x4 oa, ob;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { oa[e] = silu_f(ga[e]) * ua[e]; ob[e] = silu_f(gb[e]) * ub[e]; }
+          char* dst = reinterpret_cast<char*>(p.out) + (out_off(row) + (n0 >> 1) + gq * 32 + within) * EB;
+          if constexpr (Elem<T>::kIsF32) { *reinterpret_cast<f32x4*>(dst) = oa; *reinterpret_cast<f32x4*>(dst + 16) = ob; }
+          else *reinterpret_cast<i32x4*>(dst) = pack4(oa, ob);
+        }
+      } else if constexpr (EPI == STLLM_EPI_ROPE) {
+        constexpr int IPR = BN / 16;
+        for (int c = tid; c < 32 * IPR; c += NT) {
+          const int lrow = c / IPR, q = c - lrow * IPR;
+          const int row = m0 + trow0 + lrow;
+          const int gq = q >> 2, within = (q & 3) * 8;
+          const int c1 = gq * 64 + within, c2 = c1 + 32;
+          if (row >= p.M || n0 + c1 >= p.N) continue;
+          f32x4 xa = ldf4(lrow, c1), xb = ldf4(lrow, c1 + 4), ya = ldf4(lrow, c2), yb = ldf4(lrow, c2 + 4);
+          if (p.bias) { xa += gf4(p.bias + n0 + c1); xb += gf4(p.bias + n0 + c1 + 4); ya += gf4(p.bias + n0 + c2); yb += gf4(p.bias + n0 + c2 + 4); }
+          if (n0 + c1 < p.rope_cols) {
+            const int fi = (((n0 + c1) >> 6) & 1) * 32 + within;
+            const int pos = row % p.rope_seq;
+            const f32x4 ca = gf4(p.aux0 + pos * 64 + fi), cb = gf4(p.aux0 + pos * 64 + fi + 4);
+            const f32x4 sa = gf4(p.aux1 + pos * 64 + fi), sb = gf4(p.aux1 + pos * 64 + fi + 4);
+            const f32x4 ra = xa * ca - ya * sa, rb = xb * cb - yb * sb;
+            ya = ya * ca + xa * sa; yb = yb * cb + xb * sb;
+            xa = ra; xb = rb;
+          }
+          char* dst = reinterpret_cast<char*>(p.out) + (out_off(row) + n0 + c1) * EB;
+          if constexpr (Elem<T>::kIsF32) {
+            *reinterpret_cast<f32x4*>(dst) = xa; *reinterpret_cast<f32x4*>(dst + 16) = xb;
+            *reinterpret_cast<f32x4*>(dst + 32 * 4) = ya; *reinterpret_cast<f32x4*>(dst + 32 * 4 + 16) = yb;
+          } else {
+            *reinterpret_cast<i32x4*>(dst) = pack4(xa, xb);
+            *reinterpret_cast<i32x4*>(dst + 32 * EB) = pack4(ya, yb);
+          }
+        }
+      } else if constexpr (f32out) {
+        constexpr int IPR = BN / 4;
+        for (int c = tid; c < 32 * IPR; c += NT) {
+          const int lrow = c / IPR, cc = (c - lrow * IPR) * 4;
+          const int row = m0 + trow0 + lrow, col = n0 + cc;
+          if (row >= p.M || col >= p.N) continue;
+          f32x4 v = ldf4(lrow, cc) + (p.bias ? gf4(p.bias + col) : zero4);
+          if constexpr (EPI == STLLM_EPI_RESID) {
+            v += gf4(p.resid + (int64_t)row * p.ldr + col);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (ACT == STLLM_ACT_GELU) v[e] = gelu_erf(v[e]);
+              if constexpr (ACT == STLLM_ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+            }
+          }
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + out_off(row) + col) = v;
+        }
+      } else {
+        constexpr int IPR = BN / 8;
+        for (int c = tid; c < 32 * IPR; c += NT) {
+          const int lrow = c / IPR, cc = (c - lrow * IPR) * 8;
+          const int row = m0 + trow0 + lrow, col = n0 + cc;
+          if (row >= p.M || col >= p.N) continue;
+          f32x4 a = ldf4(lrow, cc), b = ldf4(lrow, cc + 4);
+          if (p.bias) { a += gf4(p.bias + col); b += gf4(p.bias + col + 4); }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (ACT == STLLM_ACT_GELU) { a[e] = gelu_erf(a[e]); b[e] = gelu_erf(b[e]); }
+            if constexpr (ACT == STLLM_ACT_RELU) { a[e] = fmaxf(a[e], 0.0f); b[e] = fmaxf(b[e], 0.0f); }
+          }
+          *reinterpret_cast<i32x4*>(reinterpret_cast<char*>(p.out) + (out_off(row) + col) * EB) = pack4(a, b);
+        }
+      }
+    }
+    if (contrib) {
+      // publish the partial: every wave drains its slab stores, then ONE lane releases at agent scope and sets the flag
+      wait_vmcnt<0>();
+      STLLM_BAR();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&flags[g], (unsigned)p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // next segment
+    if (c_k == nk) { c_k = 0; ++c_tile; }
+    seg_k0 = c_k;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  }
+  wait_vmcnt<0>();
+#undef STLLM_BAR
+}
+
+static int g_sk_epoch = 0;
+
+template <typename T, int BM, int BN, int EPI, int ACT = 0, bool OF32 = false>
+int launch_sk(const GemmParams& p0, hipStream_t stream) {
+  GemmParams p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int lds = SkTile<BM, BN>::kLdsBytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int64_t total = (int64_t)p.tiles_m * p.tiles_n * (p.K / (kRowBytes / Elem<T>::kBytes));
+  // every workgroup must be RESIDENT (finalisers wait for contributors): size the grid from the occupancy query, never
+  // from an assumption (MI355X_MICROARCH "Residency and cooperative launch"); one fewer per CU keeps a margin
+  static int max_wg = 0;
+  if (max_wg == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&prop, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>, SkTile<BM, BN>::NT, lds);
+    const int want = SkTile<BM, BN>::kMaxWG / 256;
+    if (per_cu > want) per_cu = want;
+    if (per_cu < 1) per_cu = 1;
+    max_wg = per_cu * prop.multiProcessorCount;
+    if (g_debug_early() & 8) fprintf(stderr, "[stllm] gemm_sk<%d,%d> occupancy %d WG/CU x %d CUs\n", BM, BN, per_cu, prop.multiProcessorCount);
+  }
+  const int grid = total < max_wg ? (int)total : max_wg;
+  p.epoch = ++g_sk_epoch;
+  hipLaunchKernelGGL((gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>), dim3(grid), dim3(SkTile<BM, BN>::NT), lds, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_gemm(stream-K)");
+  {
+    static const char* kEpi[] = {"STORE", "RESID", "SWIGLU", "ROPE", "PATCH"};
+    static char name[96];
+    static bool named = false;
+    if (!named) {
+      snprintf(name, sizeof(name), "gemm_sk_kernel<%s,%d,%d,%s,%d,%d>",
+               Elem<T>::kIsF32 ? "float" : (std::is_same<T, bf16_t>::value ? "bf16_t" : "f16_t"), BM, BN, kEpi[EPI], ACT, (int)OF32);
+      named = true;
+    }
+    stllm_set_last_kernel(name);
+  }
+  return STLLM_OK;
+}
+
+// stream-K eligibility + tile: returns 0 (off) | 1 = 128x128 | 2 = 128x256 | 3 = 256x256
+static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): -1 auto, 0 off, 1/2/3 force a tile
+static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
+static int sk_choice(const GemmParams& p, int eb) {
+  if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
+  const int mode = g_sk_mode;
+  if (mode == 0 || p.ws == nullptr) return 0;
+  if (p.ws_bytes < kSkFlagBytes + (int64_t)kSkMaxSlabWG * 128 * 128 * 4) return 0;
+  if (mode >= 1 && mode <= 3) return mode;
+  // auto (measured, profiles/r01_gemm_streamk.md): the split only pays where whole tiles cannot fill the chip AND K is
+  // long enough to amortise the hand-off — the Llama down_proj shape (M=576, N=4096, K=11008: 160 tiles of 128x128,
+  // 172 panels): 128x256 stream-K 114 us vs 186 us.  Everywhere else the persistent whole-tile kernel is faster.
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
+  const int nk = p.K * eb / kRowBytes;
+  if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 128 * 256 * 4) return 0;
+  return (t128 < 192 && t128 >= 32 && nk >= 128) ? 2 : 0;
+}
 template <typename T, int EPI, int ACT = 0, bool OF32 = false>
 int dispatch_tile(const GemmParams& p, hipStream_t stream) {
+  if constexpr (EPI != STLLM_EPI_PATCH) {
+    const int sk = sk_choice(p, Elem<T>::kBytes);
+    if (sk == 1) return launch_sk<T, 128, 128, EPI, ACT, OF32>(p, stream);
+    if (sk == 2) return launch_sk<T, 128, 256, EPI, ACT, OF32>(p, stream);
+    if (sk == 3) return launch_sk<T, 256, 256, EPI, ACT, OF32>(p, stream);
+  }
   if constexpr (EPI == STLLM_EPI_SWIGLU || EPI == STLLM_EPI_ROPE) {
     // these epilogues pair columns inside a 64-column wave tile
     if (p.M <= 64) return launch<T, 64, 128, EPI>(p, stream);
@@ -538,7 +953,9 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   p.aux0 = a->aux0; p.aux1 = a->aux1; p.frames = a->frames;
   p.rope_seq = a->rope_seq; p.rope_cols = a->rope_cols;
   p.M = a->M; p.N = a->N; p.K = K; p.act = a->act; p.out_is_f32 = a->out_is_f32;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+  if (g_debug < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); g_debug = e ? atoi(e) : 0; }
+  p.debug = g_debug;
+  p.ws = reinterpret_cast<char*>(a->workspace); p.ws_bytes = a->workspace_bytes;
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
   p.o_rpb = a->o_rows_per_batch; p.o_bs = a->o_batch_stride;
   switch (a->dtype) {
@@ -546,4 +963,14 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
     case STLLM_F16: return dispatch_epi<f16_t>(a, p, stream);
     default: return dispatch_epi<float>(a, p, stream);
   }
+}
+
+extern "C" int64_t stllm_gemm_workspace_bytes(void) { return kSkFlagBytes + (int64_t)256 * 256 * 256 * 4; }  // = 512 slabs of 128x128 too
+
+extern "C" int stllm_set_option(const char* key, int value) {
+  if (!key) return STLLM_ERR_BAD_SHAPE;
+  if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
+  stllm_set_error("stllm_set_option: unknown key %s", key);
+  return STLLM_ERR_UNSUPPORTED;
 }

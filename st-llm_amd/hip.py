@@ -21,7 +21,7 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows", "stllm_cast_rows"]
+           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_set_option"]
 
 
 def torch_dtype(d):
@@ -40,7 +40,8 @@ class GemmArgs(ctypes.Structure):
                 ("aux0", c_void_p), ("aux1", c_void_p), ("frames", c_void_p),
                 ("rope_seq", c_int), ("rope_cols", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
-                ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64)]
+                ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")
@@ -75,6 +76,8 @@ def lib():
         L.stllm_cast_rows.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]
         for n in EXPORTS[3:]:
             getattr(L, n).restype = c_int
+        L.stllm_gemm_workspace_bytes.restype = c_int64
+        L.stllm_set_option.argtypes = [c_char_p, c_int]
         _lib = L
     return _lib
 
@@ -100,6 +103,20 @@ def _req(t, dtype=None, what="tensor"):
     if t.dim() >= 1 and t.stride(-1) != 1:
         raise RuntimeError(f"{what}: last dim must be contiguous")
     return t
+
+
+_workspaces = {}
+
+
+def gemm_workspace(device):
+    """Per-device scratch of the stream-K GEMM (flags + fp32 partial slabs), zeroed once at allocation.
+    One buffer per device: all GEMM launches of this process go to torch's current stream in order."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{key}")
+        _workspaces[key] = ws
+    return ws
 
 
 class GemmProfiler:
@@ -176,6 +193,8 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         args.o_rows_per_batch, args.o_batch_stride = o_rows
     args.out, args.ldo = _p(out), out.stride(-2)
     args.M, args.N, args.K = M, N, K
+    ws = gemm_workspace(w.device)
+    args.workspace, args.workspace_bytes = _p(ws), ws.numel()
     prof, start = _profiler, None
     if prof is not None:
         key = (args.dtype, epilogue, M, N, K)
@@ -298,3 +317,7 @@ def cast_rows(x, dtype, out=None):
     _check(lib().stllm_cast_rows(dtype_code(td), _p(x), x.stride(0), _p(out), out.stride(0), M, D, _stream()),
            "stllm_cast_rows")
     return out
+
+
+def set_option(key, value):
+    _check(lib().stllm_set_option(key.encode(), int(value)), "stllm_set_option")

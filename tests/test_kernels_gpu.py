@@ -191,6 +191,70 @@ def test_gemm_two_level_rows(hip, dtype):
     check(o[:, Q:].reshape(-1, Nout), ref_t, ACC_TOL[dtype], "text rows")
 
 
+SK_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (576, 1536, 11008 // 2), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7)]
+
+
+@pytest.mark.parametrize("bm", [1, 2, 3])
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", SK_SHAPES)
+def test_gemm_stream_k(hip, dtype, bm, M, N, K):
+    """stream-K kernel forced on (both tile heights): split tiles, partial slabs, flags, N/M tails, every epilogue."""
+    hip.set_option("gemm_sk", bm)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemm_sk_kernel<")
+        check(out, ref, ACC_TOL[dtype], "sk store f32")
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "sk gelu T")
+        x = T("x", (M, N), 2.0)
+        xd = x.cuda()
+        for rep in range(2):  # run twice: flags from the previous launch (older epoch) must not satisfy the next one
+            hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+        check(xd, x.double() + 2 * ref, ACC_TOL[dtype], "sk resid x2")
+        # determinism: bit-identical across launches
+        o1 = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+        assert torch.equal(o1, out)
+    finally:
+        hip.set_option("gemm_sk", -1)
+
+
+@pytest.mark.parametrize("bm", [1, 2, 3])
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_gemm_stream_k_swiglu_rope(hip, dtype, bm):
+    from stllm_amd import pack
+    hip.set_option("gemm_sk", bm)
+    try:
+        M, K, I = 333, 1024, 1024 + 128 * 3
+        a, a64 = rnd("a", (M, K), dtype)
+        wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+        wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+        out = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
+        assert "gemm_sk_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(out, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "sk swiglu")
+        B, S, H, D = 2, 150, 4, 128
+        a, a64 = rnd("a2", (B * S, K), dtype)
+        wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+        wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+        wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+        cos, sin = pack.rope_tables(S)
+        qkv = hip.gemm(a, pack.llama_qkv(wq, wk, wv, dtype, n_heads=H), dtype=dtype, epilogue=hip.EPI_ROPE,
+                       rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D).double().cpu().view(B, S, 3, H, D)
+        c, s = O.rope_tables(S, D)
+        q = (a64 @ wq64.t()).view(B, S, H, D).transpose(1, 2)
+        k = (a64 @ wk64.t()).view(B, S, H, D).transpose(1, 2)
+        q = q * c.double() + O._rotate_half(q) * s.double()
+        k = k * c.double() + O._rotate_half(k) * s.double()
+        perm = pack.rope_head_perm(1)
+        check(qkv[:, :, 0].transpose(1, 2), q[..., perm], OUT_TOL[dtype], "sk q rope")
+        check(qkv[:, :, 1].transpose(1, 2), k[..., perm], OUT_TOL[dtype], "sk k rope")
+        check(qkv[:, :, 2], (a64 @ wv64.t()).view(B, S, H, D), OUT_TOL[dtype], "sk v")
+    finally:
+        hip.set_option("gemm_sk", -1)
+
+
 def test_gemm_rejects_bad_shapes(hip):
     a = torch.zeros((8, 100), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
