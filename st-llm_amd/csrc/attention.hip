@@ -77,25 +77,30 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
   const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
   const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
 
-  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
-    // ---- stage K tile (row-major, padded) and V tile (transposed) ---------------------------------
-    i32x4 kreg[CPT], vreg[CPT];
+  // K/V tiles are register-staged one tile AHEAD: the global loads of tile t+1 are issued before the MFMA/softmax work of
+  // tile t and only consumed (written to LDS) at the top of the next iteration — HBM/L2 latency hides under compute.
+  i32x4 kreg[CPT], vreg[CPT];
+  auto load_tile = [&](int kv0) {
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int ch = tid + c * NT;
-      const int row = ch / CPR, cc = ch - row * CPR;
+      const int cc = ch >> 5, row = ch & 31;   // consecutive lanes = consecutive keys: conflict-free transposed V writes
       const int kv = kv0 + row;
       const bool ok = (ch < NCH) && (kv < p.Skv) && (cc * 8 < D);
       i32x4 z = {0, 0, 0, 0};
       kreg[c] = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)kv * p.k_rs + cc * 8) * 2) : z;
       vreg[c] = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)kv * p.v_rs + cc * 8) * 2) : z;
     }
+  };
+  const int wave_q_last = q_blk0 + wave * 32 + 31;  // last query row of this wave (causal tile skipping)
+  if (kv_end > 0) load_tile(0);
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int ch = tid + c * NT;
       if (ch < NCH) {
-        const int row = ch / CPR, cc = ch - row * CPR;
+        const int cc = ch >> 5, row = ch & 31;
         *reinterpret_cast<i32x4*>(k_lds + row * KPITCH + cc * 16) = kreg[c];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -106,6 +111,8 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
       }
     }
     __syncthreads();
+    if (kv0 + 32 < kv_end) load_tile(kv0 + 32);
+    if (p.causal && kv0 > wave_q_last) continue;  // every key of this tile is in the future of every query of this wave
 
     // ---- S^T = K . Q^T ------------------------------------------------------------------------------
     f32x16 s;
@@ -116,34 +123,40 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
       const i32x4 kf = *reinterpret_cast<const i32x4*>(k_lds + li * KPITCH + (ks * 2 + lh) * 16);
       s = Elem<T>::mfma(kf, qf[ks], s);
     }
-    // ---- mask + online softmax (per-lane query) ------------------------------------------------------
-    float mx = kNeg;
+    // ---- mask + online softmax (per-lane query); scores stay RAW, the scale is folded into the exp2 argument ----
+    const bool need_mask = (kv0 + 32 > kvlen) || (p.causal && kv0 + 31 > q_blk0 + wave * 32);  // wave-uniform
+    if (need_mask) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      float x = s[r] * p.scale_log2;
-      const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
-      x = dead ? kNeg : x;
-      s[r] = x;
-      mx = fmaxf(mx, x);
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
+        s[r] = dead ? kNeg : s[r];
+      }
     }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx);               // running max of RAW scores (scale > 0)
+    const float mc = m_new * p.scale_log2;
     float rs = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = exp2f(s[r] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -mc));   // masked: exp2(-huge) == 0
       s[r] = pv;
       rs += pv;
     }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
+    if (__any(m_new != m_run)) {   // rescale only when some query's running max moved (wave-uniform branch)
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+      l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < DB; ++i)
+      for (int i = 0; i < DB; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += rs;
 
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
 #pragma unroll
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
       i32x4 pf;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        pf[e] = (int)((uint32_t)Elem<T>::pack(s[a * 8 + 2 * e]) | ((uint32_t)Elem<T>::pack(s[a * 8 + 2 * e + 1]) << 16));
+        pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
 #pragma unroll
       for (int i = 0; i < DB; ++i) {
         const char* vp = v_lds + (i * 32 + li) * VPITCH + (16 * a + 4 * lh) * 2;
@@ -174,8 +187,8 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
         const int d0 = i * 32 + 8 * g + 4 * lh;
         if (d0 < D) {  // D % 4 == 0
           uint2 pk;
-          pk.x = (uint32_t)Elem<T>::pack(o[i][4 * g + 0] * inv) | ((uint32_t)Elem<T>::pack(o[i][4 * g + 1] * inv) << 16);
-          pk.y = (uint32_t)Elem<T>::pack(o[i][4 * g + 2] * inv) | ((uint32_t)Elem<T>::pack(o[i][4 * g + 3] * inv) << 16);
+          pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+          pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(op + d0) = pk;
         }
       }
@@ -248,7 +261,7 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
   //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
   if (p.D == 88) return p.Sq <= 32 ? launch_mfma<T, 96, 1>(p, stream) : launch_mfma<T, 96, 3>(p, stream);  // Sq<=32: BT-Adapter temporal attention
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
-  if (p.D == 128) return launch_mfma<T, 128, 3>(p, stream);
+  if (p.D == 128) return launch_mfma<T, 128, 2>(p, stream);   // 64-row blocks: 9 x 32 heads = 288 blocks at S=576
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
   return STLLM_ERR_UNSUPPORTED;
 }

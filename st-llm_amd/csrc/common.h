@@ -41,6 +41,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 struct bf16_t { uint16_t v; };   // tag types for templates (storage = 2 bytes)
 struct f16_t { uint16_t v; };
@@ -67,7 +70,12 @@ template <typename T> struct Elem;
 template <> struct Elem<bf16_t> {
   static constexpr int kBytes = 2;
   static constexpr bool kIsF32 = false;
-  __device__ static __forceinline__ uint16_t pack(float f) { return f32_to_bf16_bits(f); }
+  __device__ static __forceinline__ uint16_t pack(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }  // RNE
+  // two values -> one dword: a single v_cvt_pk_bf16_f32 (round-to-nearest-even, == torch .to(bfloat16))
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
   __device__ static __forceinline__ float unpack(uint16_t h) { return bf16_bits_to_f32(h); }
   __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -77,6 +85,10 @@ template <> struct Elem<f16_t> {
   static constexpr int kBytes = 2;
   static constexpr bool kIsF32 = false;
   __device__ static __forceinline__ uint16_t pack(float f) { return f32_to_f16_bits(f); }
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {   // v_cvt_pk_f16_f32, RNE
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
   __device__ static __forceinline__ float unpack(uint16_t h) { return f16_bits_to_f32(h); }
   __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -86,6 +98,7 @@ template <> struct Elem<float> {
   static constexpr int kBytes = 4;
   static constexpr bool kIsF32 = true;
   __device__ static __forceinline__ uint16_t pack(float) { return 0; }  // never used: fp32 outputs are stored as-is
+  __device__ static __forceinline__ uint32_t pack2(float, float) { return 0; }
   // One 16-byte fragment = 4 consecutive k of this lane's half; the k <-> (step, half) slot map is
   // the same for A and B, so 4 exact-fp32 MFMAs (K=2 each) consume one fragment pair.
   __device__ static __forceinline__ f32x16 mfma(i32x4 a, i32x4 b, f32x16 c) {

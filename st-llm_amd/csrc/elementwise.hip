@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
       reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo)[c] = v;
     } else {
       uint2 pk;
-      pk.x = (uint32_t)Elem<T>::pack(v.x) | ((uint32_t)Elem<T>::pack(v.y) << 16);
-      pk.y = (uint32_t)Elem<T>::pack(v.z) | ((uint32_t)Elem<T>::pack(v.w) << 16);
+      pk.x = Elem<T>::pack2(v.x, v.y);
+      pk.y = Elem<T>::pack2(v.z, v.w);
       reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + (int64_t)row * ldo)[c] = pk;
     }
   }

@@ -87,7 +87,7 @@ __device__ __forceinline__ i32x4 patch_chunk(const float* __restrict__ frames, i
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      r[e] = (int)((uint32_t)Elem<T>::pack(v[2 * e]) | ((uint32_t)Elem<T>::pack(v[2 * e + 1]) << 16));
+      r[e] = (int)(Elem<T>::pack2(v[2 * e], v[2 * e + 1]));
   }
   return r;
 }
@@ -324,10 +324,10 @@ __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kerne
       auto gf4 = [&](const float* ptr) { return *reinterpret_cast<const f32x4*>(ptr); };
       auto pack4 = [&](f32x4 a, f32x4 b) {  // 8 values -> 16 bytes of the compute dtype
         i32x4 o;
-        o[0] = (int)((uint32_t)Elem<T>::pack(a[0]) | ((uint32_t)Elem<T>::pack(a[1]) << 16));
-        o[1] = (int)((uint32_t)Elem<T>::pack(a[2]) | ((uint32_t)Elem<T>::pack(a[3]) << 16));
-        o[2] = (int)((uint32_t)Elem<T>::pack(b[0]) | ((uint32_t)Elem<T>::pack(b[1]) << 16));
-        o[3] = (int)((uint32_t)Elem<T>::pack(b[2]) | ((uint32_t)Elem<T>::pack(b[3]) << 16));
+        o[0] = (int)(Elem<T>::pack2(a[0], a[1]));
+        o[1] = (int)(Elem<T>::pack2(a[2], a[3]));
+        o[2] = (int)(Elem<T>::pack2(b[0], b[1]));
+        o[3] = (int)(Elem<T>::pack2(b[2], b[3]));
         return o;
       };
       f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) 
       auto gf4 = [&](const float* ptr) { return *reinterpret_cast<const f32x4*>(ptr); };
       auto pack4 = [&](f32x4 a, f32x4 b) {
         i32x4 o;
-        o[0] = (int)((uint32_t)Elem<T>::pack(a[0]) | ((uint32_t)Elem<T>::pack(a[1]) << 16));
-        o[1] = (int)((uint32_t)Elem<T>::pack(a[2]) | ((uint32_t)Elem<T>::pack(a[3]) << 16));
-        o[2] = (int)((uint32_t)Elem<T>::pack(b[0]) | ((uint32_t)Elem<T>::pack(b[1]) << 16));
-        o[3] = (int)((uint32_t)Elem<T>::pack(b[2]) | ((uint32_t)Elem<T>::pack(b[3]) << 16));
+        o[0] = (int)(Elem<T>::pack2(a[0], a[1]));
+        o[1] = (int)(Elem<T>::pack2(a[2], a[3]));
+        o[2] = (int)(Elem<T>::pack2(b[0], b[1]));
+        o[3] = (int)(Elem<T>::pack2(b[2], b[3]));
         return o;
       };
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
         reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
       } else {
         uint2 pk;
-        pk.x = (uint32_t)Elem<T>::pack(o.x) | ((uint32_t)Elem<T>::pack(o.y) << 16);
-        pk.y = (uint32_t)Elem<T>::pack(o.z) | ((uint32_t)Elem<T>::pack(o.w) << 16);
+        pk.x = Elem<T>::pack2(o.x, o.y);
+        pk.y = Elem<T>::pack2(o.z, o.w);
         reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
       }
     }

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the attention shapes on the hot path (config 2).  GPU only."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stllm_amd import hip
+
+CASES = [("vit", 16, 16, 257, 257, 88, False, 39), ("llama", 1, 32, 576, 576, 128, True, 32),
+         ("qf_self", 16, 12, 32, 32, 64, False, 12), ("qf_cross", 16, 12, 32, 257, 64, False, 6)]
+for name, B, H, Sq, Skv, D, causal, per_clip in CASES:
+    dt = torch.bfloat16
+    if Sq == Skv:
+        buf = torch.randn(B * Sq, 3 * H * D, device="cuda").to(dt)
+        q, k, v = buf[:, :H * D], buf[:, H * D:2 * H * D], buf[:, 2 * H * D:]
+    else:
+        q = torch.randn(B * Sq, H * D, device="cuda").to(dt)
+        kv = torch.randn(B * Skv, 2 * H * D, device="cuda").to(dt)
+        k, v = kv[:, :H * D], kv[:, H * D:]
+    out = hip.attention(q, k, v, B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=D ** -0.5, causal=causal)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        hip.attention(q, k, v, B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=D ** -0.5, causal=causal, out=out)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 20
+    fl = 4.0 * B * H * Sq * Skv * D * (0.5 if causal else 1.0)
+    print(f"{name:9s} B={B:3d} H={H:3d} Sq={Sq:4d} Skv={Skv:4d} D={D:4d} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF   x{per_clip} = {ms * per_clip:.3f} ms")
