@@ -262,3 +262,37 @@ def test_config3_global_local_t64_vs_oracle():
     err = float((out.logits.cpu() - ref["logits"])[valid].abs().max())
     print(f"\n[config3-shape fp32] S={out.logits.shape[1]} logits max-abs err {err:.3e}")
     assert err <= 1e-2
+
+
+def test_c1_full_size_vs_reference():
+    """BASELINE config 1 at FULL SIZE (B1 T4, EVA-CLIP-g 39 blocks + 12-layer Q-Former + Vicuna-7B 32 layers): the
+    fixture holds a summary of the logits the REFERENCE's own STLLMForCausalLM produced on CPU (fp32) with the same
+    synthetic weights (tests/golden/make_fixtures.py c1_full).  Verify mode must be within the north-star's 1e-2;
+    the fast modes are measured and bounded loosely."""
+    from stllm_amd import runtime
+    g = golden("c1_full")
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False,
+               mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=39, qf_layers=12, llm_layers=32)
+    samples = _samples_from_fixture(dict(before=g["before"], after=g["after"], answer=np.concatenate([g["answer"], [[2]]], axis=1),
+                                         qtext=np.zeros((1, 0), dtype=np.int64)), 4, False)
+    res = {}
+    for mode in ("fp32", "fp16", "bf16"):
+        with runtime.use_dtype(mode):
+            for m in (model.model.stllm_model.visual_encoder, model.model.stllm_model.Qformer.bert, model.model):
+                m.repack()
+            model._lm_packed = {}
+            out = model(samples=samples)
+        lg = out.logits[0].float().cpu()
+        err = float(np.abs(lg[::3, ::499].numpy() - g["logits_slice"]).max())
+        top = lg.topk(5, dim=-1)
+        agree = float((top.indices[:, 0].numpy() == g["top_ids"][:, 0]).mean())
+        res[mode] = (err, agree, float(out.loss.item()))
+        print(f"\n[c1_full {mode}] logits max-abs err {err:.3e} (abs-max {g['logits_stats'][1]:.2f}), top-1 agreement "
+              f"{agree:.3f}, loss {out.loss.item():.5f} vs {g['loss'][0]:.5f}")
+        if mode == "fp32":
+            assert err <= 1e-2 and agree >= 0.99
+            assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
+            assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
+            assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
+    assert res["fp16"][0] <= 0.2 and res["bf16"][0] <= 1.5
