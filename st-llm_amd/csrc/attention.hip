@@ -196,6 +196,162 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
   }
 }
 
+// ---- resident-K/V variant for short key sequences (ViT: 257 keys, Q-Former cross-attention) ----------------
+// The whole K (row-major, padded rows) and V^T of one (batch, head) are staged into LDS ONCE (<= 116 KiB for 288 keys x
+// 96 dims), one barrier, then every wave walks all key tiles for its own 32 query rows with NO further barriers: waves
+// run decoupled, so LDS/MFMA/VALU latencies of one wave hide under the others (PMC on the tiled kernel: 55 % of wave
+// time parked at barriers/waits).  One workgroup per (batch, head): 16 frames x 16 heads = 256 workgroups = one per CU.
+template <typename T, int DP, int SKV_MAX>
+__global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) {
+  constexpr int KS = DP / 16, DB = DP / 32;
+  constexpr int KPITCH = DP * 2 + 16;
+  constexpr int VPITCH = SKV_MAX * 2 + 8;
+  constexpr int CPR = DP / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* k_lds = smem;
+  char* v_lds = smem + SKV_MAX * KPITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int D = p.D;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const int n_tiles = (kvlen + 31) >> 5;
+  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
+  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
+
+  // ---- stage K and V^T once (rows >= Skv and dims >= D are zero) ----------------------------------------
+  for (int ch = tid; ch < n_tiles * 32 * CPR; ch += blockDim.x) {
+    const int t = ch / (32 * CPR), rem = ch - t * (32 * CPR);
+    const int cc = rem >> 5, row = t * 32 + (rem & 31);
+    const bool ok = (row < p.Skv) && (cc * 8 < D);
+    i32x4 z = {0, 0, 0, 0};
+    const i32x4 kv_ = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)row * p.k_rs + cc * 8) * 2) : z;
+    const i32x4 vv = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)row * p.v_rs + cc * 8) * 2) : z;
+    *reinterpret_cast<i32x4*>(k_lds + row * KPITCH + cc * 16) = kv_;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = (uint32_t)vv[e];
+      *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + row * 2) = (uint16_t)(w & 0xffff);
+      *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + row * 2) = (uint16_t)(w >> 16);
+    }
+  }
+  __syncthreads();
+
+  for (int qt = wave; qt * 32 < p.Sq; qt += nwaves) {
+    const int qrow = qt * 32 + li;
+    i32x4 qf[KS];
+    {
+      const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + lh * 8;
+        i32x4 z = {0, 0, 0, 0};
+        qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
+      }
+    }
+    f32x16 o[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+    float m_run = kNeg, l_run = 0.0f;
+    const int t_end = p.causal ? min(n_tiles, qt + 1) : n_tiles;
+    for (int t = 0; t < t_end; ++t) {
+      const int kv0 = t * 32;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(k_lds + (kv0 + li) * KPITCH + (ks * 2 + lh) * 16);
+        s = Elem<T>::mfma(kf, qf[ks], s);
+      }
+      const bool need_mask = (kv0 + 32 > kvlen) || (p.causal && kv0 + 31 > qt * 32);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
+          s[r] = dead ? kNeg : s[r];
+        }
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = m_new * p.scale_log2;
+      float rs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -mc));
+        s[r] = pv;
+        rs += pv;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += rs;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        i32x4 pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
+#pragma unroll
+        for (int i = 0; i < DB; ++i) {
+          const char* vp = v_lds + (i * 32 + li) * VPITCH + (kv0 + 16 * a + 4 * lh) * 2;
+          const i32x2 lo = *reinterpret_cast<const i32x2*>(vp);
+          const i32x2 hi = *reinterpret_cast<const i32x2*>(vp + 16);
+          const i32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
+          o[i] = Elem<T>::mfma(vf, pf, o[i]);
+        }
+      }
+    }
+    if (qrow < p.Sq) {
+      const float inv = 1.0f / l_run;
+      uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+#pragma unroll
+      for (int i = 0; i < DB; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = i * 32 + 8 * g + 4 * lh;
+          if (d0 < D) {
+            uint2 pk;
+            pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+            pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + d0) = pk;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int DP, int SKV_MAX>
+int launch_resident(const AttnParams& p, hipStream_t stream) {
+  constexpr int lds = SKV_MAX * (DP * 2 + 16) + DP * (SKV_MAX * 2 + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<T, DP, SKV_MAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  int nw = (p.Sq + 31) / 32;
+  if (nw > 12) nw = 12;
+  dim3 grid(1, p.H, p.B), block(64 * nw);
+  hipLaunchKernelGGL((attn_resident_kernel<T, DP, SKV_MAX>), grid, block, lds, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention(resident)");
+  return STLLM_OK;
+}
+
 // ---- exact fp32 path: one wave per query row -----------------------------------------------------
 constexpr int kF32MaxKv = 2048;
 
@@ -259,7 +415,11 @@ template <typename T>
 int dispatch(const AttnParams& p, hipStream_t stream) {
   // NW picked so that 32*NW divides the common sequence lengths with little waste:
   //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
-  if (p.D == 88) return p.Sq <= 32 ? launch_mfma<T, 96, 1>(p, stream) : launch_mfma<T, 96, 3>(p, stream);  // Sq<=32: BT-Adapter temporal attention
+  if (p.D == 88) {
+    if (p.Sq <= 32) return launch_mfma<T, 96, 1>(p, stream);                       // BT-Adapter temporal attention
+    if (p.Skv <= 288 && !p.causal) return launch_resident<T, 96, 288>(p, stream);  // ViT: K/V of a head resident in LDS
+    return launch_mfma<T, 96, 3>(p, stream);
+  }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
   if (p.D == 128) return launch_mfma<T, 128, 2>(p, stream);   // 64-row blocks: 9 x 32 heads = 288 blocks at S=576
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
