@@ -147,14 +147,17 @@ def main():
     torch.cuda.synchronize()
     S = out.logits.shape[1]
     prof = None
-    if rank == 0 and not args.no_roofline:
-        prof = hip.GemmProfiler()
-        hip.set_profiler(prof)
+    if not args.no_roofline:
+        # calibration step on EVERY rank (it contains the all-gather collective); only rank 0 times its GEMM launches
+        if rank == 0:
+            prof = hip.GemmProfiler()
+            hip.set_profiler(prof)
         step()
         torch.cuda.synchronize()
-        cal = prof.summary()
-        prof.target = max(cal, key=lambda k: cal[k]["total_ms"])
-        prof.mode, prof.records = "target", {}
+        if rank == 0:
+            cal = prof.summary()
+            prof.target = max(cal, key=lambda k: cal[k]["total_ms"])
+            prof.mode, prof.records = "target", {}
     # ---- timed region: EXACTLY K steps between barrier + synchronize ---------------------------------
     sync()
     t0 = time.perf_counter()
