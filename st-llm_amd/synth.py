@@ -16,6 +16,17 @@ import torch
 
 _M32 = 0xFFFFFFFF
 _CHUNK = 1 << 24
+_CACHE = None          # optional {(name, seed, numel, std, mean): fp32 CPU tensor}; test-suites regenerate the same tensors often
+_CACHE_BYTES = 0
+_CACHE_LIMIT = 12 << 30
+
+
+def enable_cache(limit_bytes=12 << 30):
+    """Memoise generated CPU tensors (generation is ~20 M elements/s on the host)."""
+    global _CACHE, _CACHE_LIMIT
+    if _CACHE is None:
+        _CACHE = {}
+    _CACHE_LIMIT = limit_bytes
 
 
 def _hash32(x: torch.Tensor) -> torch.Tensor:
@@ -35,9 +46,16 @@ def name_key(name: str, seed: int) -> int:
 
 def normal_(t: torch.Tensor, name: str, seed: int = 0, std: float = 0.02, mean: float = 0.0) -> torch.Tensor:
     """Fill `t` in place (any float dtype, any device) from (name, seed)."""
+    global _CACHE_BYTES
     key = name_key(name, seed)
     flat = t.view(-1)
     n = flat.numel()
+    ck = (name, seed, n, float(std), float(mean))
+    if _CACHE is not None and t.device.type == "cpu":
+        hit = _CACHE.get(ck)
+        if hit is not None:
+            flat.copy_(hit)
+            return t
     scale = std / 209.02152999054  # sqrt(8 * (256^2 - 1) / 12)
     for s in range(0, n, _CHUNK):
         e = min(n, s + _CHUNK)
@@ -49,6 +67,9 @@ def normal_(t: torch.Tensor, name: str, seed: int = 0, std: float = 0.02, mean: 
         if mean != 0.0:
             v = v + mean
         flat[s:e] = v.to(t.dtype)
+    if _CACHE is not None and t.device.type == "cpu" and t.dtype == torch.float32 and _CACHE_BYTES + 4 * n <= _CACHE_LIMIT:
+        _CACHE[ck] = flat.clone()
+        _CACHE_BYTES += 4 * n
     return t
 
 

@@ -1,0 +1,170 @@
+"""TEST-ONLY stand-in for ``stllm_amd.hip``: the same call surface implemented with plain fp32 torch ops on the CPU.
+
+Used by ``tests/test_host_orchestration_cpu.py`` to run the *product's host code* (module graph, weight packers,
+index tables, 2-level row indexing, frame-parallel + clip-parallel logic under gloo) without a GPU and compare it
+with the oracle.  It is NOT a fallback: nothing in ``st-llm_amd/`` imports it, and it lives under ``tests/``.
+Every function restates the contract documented in include/stllm_hip.h (incl. the packed weight layouts)."""
+import contextlib
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF16, F16, F32 = 0, 1, 2
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_ROPE, EPI_PATCH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+def torch_dtype(d):
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(d, d) if isinstance(d, str) else d
+
+
+def _rows(t, n, rows):
+    """row indices of the logical rows 0..n-1 inside the 2-D buffer `t` under (rows_per_batch, batch_stride)"""
+    if rows is None:
+        return torch.arange(n)
+    rpb, bs = rows
+    m = torch.arange(n)
+    return (m // rpb) * (bs // t.stride(-2)) + (m % rpb)
+
+
+def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
+         rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None, a_rows=None, o_rows=None):
+    td = torch_dtype(dtype)
+    wf = w.float()
+    N = w.shape[0]
+    if epilogue == EPI_PATCH:
+        n = n_frames
+        cols = frames.float().reshape(n, 3, 16, 14, 16, 14).permute(0, 2, 4, 1, 3, 5).reshape(n * 256, 588)
+        acc = cols.to(td).float() @ wf[:, :588].t()
+        acc = acc + (bias if bias is not None else 0)
+        o = out.view(n, 257, -1)
+        o[:, 1:] = acc.view(n, 256, N) + pos_embed[1:].view(1, 256, N)
+        return out
+    if M is None:
+        M = a.shape[0]
+    A = a[_rows(a, M, a_rows)].float()
+    acc = A @ wf.t()
+    if bias is not None:
+        acc = acc + bias
+    if epilogue == EPI_RESID:
+        res = resid[:M].float() + acc
+        dst = resid if out is None else out
+        dst[_rows(dst, M, o_rows)] = res
+        return dst
+    if epilogue == EPI_SWIGLU:
+        g = acc.view(M, N // 64, 2, 32)
+        val = (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N // 2)
+    elif epilogue == EPI_ROPE:
+        cos, sin = rope
+        x = acc.view(M, N // 64, 2, 32).clone()
+        grp = torch.arange(N // 64)
+        pos = torch.arange(M) % rope_seq
+        fi = (grp % 2)[:, None] * 32 + torch.arange(32)[None, :]             # [groups, 32]
+        c, s = cos[pos][:, fi], sin[pos][:, fi]                                # [M, groups, 32]
+        live = (grp * 64 < rope_cols)[None, :, None]
+        x1, x2 = x[:, :, 0], x[:, :, 1]
+        y1 = torch.where(live, x1 * c - x2 * s, x1)
+        y2 = torch.where(live, x2 * c + x1 * s, x2)
+        val = torch.stack((y1, y2), dim=2).reshape(M, N)
+    else:
+        val = acc
+        if act == ACT_GELU:
+            val = 0.5 * val * (1.0 + torch.erf(val / math.sqrt(2.0)))
+        elif act == ACT_RELU:
+            val = torch.relu(val)
+    odt = torch.float32 if (out_f32 and epilogue == EPI_STORE) else td
+    if out is None:
+        return val.to(odt)
+    out[_rows(out, M, o_rows)] = val.to(out.dtype)
+    return out
+
+
+def layernorm(x, gamma, beta, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
+    y = F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps)
+    return (y.to(torch_dtype(dtype)) if want_t or out_t is not None else None), (y if want_f32 or out_f32 is not None else None)
+
+
+def rmsnorm(x, gamma, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
+    xf = x.float()
+    y = gamma.float() * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps))
+    return (y.to(torch_dtype(dtype)) if want_t else None), (y if want_f32 else None)
+
+
+def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, out=None, q_strides=None, k_strides=None,
+              v_strides=None):
+    def heads(t, S):
+        return t[:, : H * D].float().reshape(B, S, H, D).transpose(1, 2) if t.shape[0] == B * S else None
+    qh, kh, vh = heads(q, Sq), heads(k, Skv), heads(v, Skv)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(Sq, Skv).triu(1).bool(), float("-inf"))
+    if kv_len is not None:
+        dead = torch.arange(Skv)[None, :] >= kv_len.long()[:, None]
+        s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    o = (s.softmax(-1) @ vh).transpose(1, 2).reshape(B * Sq, H * D).to(q.dtype)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def gather_rows(src_a, idx_a, *, src_b=None, add=None, idx_add=None, out=None, scale=1.0):
+    idx = idx_a.long()
+    res = torch.empty((idx.numel(), src_a.shape[-1]))
+    pos = idx >= 0
+    res[pos] = src_a[idx[pos]].float()
+    if (~pos).any():
+        res[~pos] = src_b[-idx[~pos] - 1].float()
+    if add is not None:
+        res = res + add[idx_add.long()].float()
+    if scale != 1.0:
+        res = res * scale
+    if out is not None:
+        out[: res.shape[0]] = res
+        return out
+    return res
+
+
+def mean_t(x):
+    return x.float().mean(dim=1)
+
+
+def vit_cls_rows(cls, pos, x, n_frames):
+    x.view(n_frames, 257, -1)[:, 0] = cls + pos[0]
+
+
+def cosine_rows(a, b, idx_a=None, idx_b=None, n_rows=None):
+    aa = a if idx_a is None else a[idx_a.long()]
+    bb = b if idx_b is None else b[idx_b.long()]
+    n = n_rows if n_rows is not None else aa.shape[0]
+    aa, bb = aa[:n].float(), bb[:n].float()
+    return 2 - 2 * (F.normalize(aa, dim=-1) * F.normalize(bb, dim=-1)).sum(-1)
+
+
+def cross_entropy_rows(logits, labels):
+    return F.cross_entropy(logits.float(), labels.long(), ignore_index=-100, reduction="none")
+
+
+def cast_rows(x, dtype, out=None):
+    return x.to(torch_dtype(dtype))
+
+
+def set_profiler(p):
+    pass
+
+
+@contextlib.contextmanager
+def installed():
+    """Monkey-patch stllm_amd.hip's compute entry points with the functions above (tests only)."""
+    from stllm_amd import hip
+    names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
+             "cross_entropy_rows", "cast_rows"]
+    saved = {n: getattr(hip, n) for n in names}
+    try:
+        for n in names:
+            setattr(hip, n, globals()[n])
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(hip, n, f)

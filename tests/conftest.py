@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from stllm_amd import synth
+    synth.enable_cache()  # the suites regenerate the same named full-width tensors many times
 
 
 def pytest_collection_modifyitems(config, items):

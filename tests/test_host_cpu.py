@@ -26,7 +26,7 @@ def test_abi_exports_match_header():
     from stllm_amd import hip
     L = hip.lib()
     header = open(os.path.join(ROOT, "include", "stllm_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(stllm_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(stllm_[a-z0-9_]+)\s*\(", header, re.M))
     assert declared, "no declarations parsed"
     for name in sorted(declared):
         assert hasattr(L, name), f"libstllm_hip.so does not export {name}"
