@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--vit-streams", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +129,7 @@ def main():
     model = build_model(device, args)
     sm = model.model.stllm_model
     sm.set_frame_parallel(rank, world)
+    sm.visual_encoder.frame_streams = args.vit_streams
     B, T = world, args.frames
     samples = make_samples(B, T, device)
     Lvis = T * 32
@@ -203,7 +205,7 @@ def main():
                                "all_gemm_kernels_one_step": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
                                                                  "tflops": round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1)}
                                                              for k, v in sorted(cal.items(), key=lambda kv: -kv[1]["total_ms"])}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0, N=1 only
             res["cpu_baseline"] = cpu_baseline(T, S)
         print(json.dumps(res), flush=True)
     if world > 1:

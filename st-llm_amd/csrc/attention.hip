@@ -203,6 +203,8 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
 // time parked at barriers/waits).  One workgroup per (batch, head): 16 frames x 16 heads = 256 workgroups = one per CU.
 template <typename T, int DP, int SKV_MAX>
 __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) {
+  // SKV_MAX = keys staged per pass (the "window").  Keys beyond one window are handled by further passes (one pair of
+  // barriers per window instead of per 32-key tile); blockIdx.x selects a chunk of blockDim.x/64 query tiles.
   constexpr int KS = DP / 16, DB = DP / 32;
   constexpr int KPITCH = DP * 2 + 16;
   constexpr int VPITCH = SKV_MAX * 2 + 8;
@@ -216,55 +218,67 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
   const int b = blockIdx.z, h = blockIdx.y;
   const int D = p.D;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
-  const int n_tiles = (kvlen + 31) >> 5;
   const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
   const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
+  // heavy (late, causal) chunks first: blockIdx.x counts down the query chunks
+  const int chunk = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int qt = chunk * nwaves + wave;                 // this wave's query tile
+  const bool q_live = qt * 32 < p.Sq;
+  const int qrow = qt * 32 + li;
+  int kv_block_end = kvlen;                             // keys any wave of this block can see
+  if (p.causal) kv_block_end = min(kv_block_end, (chunk + 1) * nwaves * 32);
 
-  // ---- stage K and V^T once (rows >= Skv and dims >= D are zero) ----------------------------------------
-  for (int ch = tid; ch < n_tiles * 32 * CPR; ch += blockDim.x) {
-    const int t = ch / (32 * CPR), rem = ch - t * (32 * CPR);
-    const int cc = rem >> 5, row = t * 32 + (rem & 31);
-    const bool ok = (row < p.Skv) && (cc * 8 < D);
-    i32x4 z = {0, 0, 0, 0};
-    const i32x4 kv_ = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)row * p.k_rs + cc * 8) * 2) : z;
-    const i32x4 vv = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)row * p.v_rs + cc * 8) * 2) : z;
-    *reinterpret_cast<i32x4*>(k_lds + row * KPITCH + cc * 16) = kv_;
+  i32x4 qf[KS];
+  {
+    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t w = (uint32_t)vv[e];
-      *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + row * 2) = (uint16_t)(w & 0xffff);
-      *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + row * 2) = (uint16_t)(w >> 16);
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + lh * 8;
+      i32x4 z = {0, 0, 0, 0};
+      qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
     }
   }
-  __syncthreads();
-
-  for (int qt = wave; qt * 32 < p.Sq; qt += nwaves) {
-    const int qrow = qt * 32 + li;
-    i32x4 qf[KS];
-    {
-      const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
+  f32x16 o[DB];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int d0 = ks * 16 + lh * 8;
-        i32x4 z = {0, 0, 0, 0};
-        qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+  float m_run = kNeg, l_run = 0.0f;
+
+  for (int win0 = 0; win0 < kv_block_end; win0 += SKV_MAX) {
+    const int win_keys = min(SKV_MAX, kv_block_end - win0);
+    const int n_tiles = (win_keys + 31) >> 5;
+    if (win0 > 0) __syncthreads();   // previous window fully consumed
+    // ---- stage this window's K and V^T (rows >= Skv and dims >= D are zero) ------------------------------
+    for (int ch = tid; ch < n_tiles * 32 * CPR; ch += blockDim.x) {
+      const int t = ch / (32 * CPR), rem = ch - t * (32 * CPR);
+      const int cc = rem >> 5, lrow = t * 32 + (rem & 31);
+      const int row = win0 + lrow;
+      const bool ok = (row < p.Skv) && (cc * 8 < D);
+      i32x4 z = {0, 0, 0, 0};
+      const i32x4 kv_ = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)row * p.k_rs + cc * 8) * 2) : z;
+      const i32x4 vv = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)row * p.v_rs + cc * 8) * 2) : z;
+      *reinterpret_cast<i32x4*>(k_lds + lrow * KPITCH + cc * 16) = kv_;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t w = (uint32_t)vv[e];
+        *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + lrow * 2) = (uint16_t)(w & 0xffff);
+        *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + lrow * 2) = (uint16_t)(w >> 16);
       }
     }
-    f32x16 o[DB];
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
-    float m_run = kNeg, l_run = 0.0f;
-    const int t_end = p.causal ? min(n_tiles, qt + 1) : n_tiles;
+    __syncthreads();
+    if (!q_live) continue;
+    {
+    int t_end = n_tiles;
+    if (p.causal) t_end = min(n_tiles, qt + 1 - (win0 >> 5));   // tiles up to this wave's diagonal
     for (int t = 0; t < t_end; ++t) {
-      const int kv0 = t * 32;
+      const int kv0 = win0 + t * 32;   // global key index of the tile; LDS rows are window-relative
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const i32x4 kf = *reinterpret_cast<const i32x4*>(k_lds + (kv0 + li) * KPITCH + (ks * 2 + lh) * 16);
+        const i32x4 kf = *reinterpret_cast<const i32x4*>(k_lds + (t * 32 + li) * KPITCH + (ks * 2 + lh) * 16);
         s = Elem<T>::mfma(kf, qf[ks], s);
       }
       const bool need_mask = (kv0 + 32 > kvlen) || (p.causal && kv0 + 31 > qt * 32);
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
         for (int e = 0; e < 4; ++e) pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
 #pragma unroll
         for (int i = 0; i < DB; ++i) {
-          const char* vp = v_lds + (i * 32 + li) * VPITCH + (kv0 + 16 * a + 4 * lh) * 2;
+          const char* vp = v_lds + (i * 32 + li) * VPITCH + (t * 32 + 16 * a + 4 * lh) * 2;
           const i32x2 lo = *reinterpret_cast<const i32x2*>(vp);
           const i32x2 hi = *reinterpret_cast<const i32x2*>(vp + 16);
           const i32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
@@ -315,20 +329,21 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
         }
       }
     }
-    if (qrow < p.Sq) {
-      const float inv = 1.0f / l_run;
-      uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+    }
+  }
+  if (q_live && qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
 #pragma unroll
-      for (int i = 0; i < DB; ++i) {
+    for (int i = 0; i < DB; ++i) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = i * 32 + 8 * g + 4 * lh;
-          if (d0 < D) {
-            uint2 pk;
-            pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
-            pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + d0) = pk;
-          }
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * lh;
+        if (d0 < D) {
+          uint2 pk;
+          pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+          pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(op + d0) = pk;
         }
       }
     }
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
 }
 
 template <typename T, int DP, int SKV_MAX>
-int launch_resident(const AttnParams& p, hipStream_t stream) {
+int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
   constexpr int lds = SKV_MAX * (DP * 2 + 16) + DP * (SKV_MAX * 2 + 8);
   static bool attr_set = false;
   if (!attr_set) {
@@ -344,9 +359,11 @@ int launch_resident(const AttnParams& p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  int nw = (p.Sq + 31) / 32;
+  const int q_tiles = (p.Sq + 31) / 32;
+  int nw = nw_req > 0 ? nw_req : q_tiles;
   if (nw > 12) nw = 12;
-  dim3 grid(1, p.H, p.B), block(64 * nw);
+  if (nw > q_tiles) nw = q_tiles;
+  dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw);
   hipLaunchKernelGGL((attn_resident_kernel<T, DP, SKV_MAX>), grid, block, lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_attention(resident)");
   return STLLM_OK;
@@ -421,7 +438,7 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
     return launch_mfma<T, 96, 3>(p, stream);
   }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
-  if (p.D == 128) return launch_mfma<T, 128, 2>(p, stream);   // 64-row blocks: 9 x 32 heads = 288 blocks at S=576
+  if (p.D == 128) return launch_resident<T, 128, 128>(p, stream, 3);  // 128-key windows (2 workgroups/CU), 96 queries per workgroup
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
   return STLLM_ERR_UNSUPPORTED;
 }

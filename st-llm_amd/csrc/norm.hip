@@ -72,9 +72,96 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
   }
 }
 
+// Few-row variant (Llama prefill: 576 rows x 4096): one WORKGROUP (4 waves) per row so that 576 rows still put 576
+// workgroups on the 256 CUs; cross-wave reduction through LDS.
+template <typename T, bool RMS, int NV>
+__global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__ x, int64_t ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, void* __restrict__ out_t, int64_t ldo_t,
+                                                       float* __restrict__ out_f, int64_t ldo_f, int M, int D) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int row = blockIdx.x;
+  const int nvec = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+  float4 v[NV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = tid + i * 256;
+    v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    else s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[0][w] = s;
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  float mean = 0.0f, rstd;
+  if constexpr (RMS) {
+    rstd = rsqrtf(s / (float)D + eps);
+  } else {
+    mean = s / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = tid + i * 256;
+      if (c < nvec) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[1][w] = q;
+    __syncthreads();
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    rstd = rsqrtf(q / (float)D + eps);
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = tid + i * 256;
+    if (c >= nvec) continue;
+    const float4 g = g4[c];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * g.x; o.y = (v[i].y - mean) * rstd * g.y;
+    o.z = (v[i].z - mean) * rstd * g.z; o.w = (v[i].w - mean) * rstd * g.w;
+    if constexpr (!RMS) {
+      const float4 b = b4[c];
+      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+    }
+    if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
+    if (out_t) {
+      if constexpr (Elem<T>::kIsF32) {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
+      } else {
+        uint2 pk;
+        pk.x = Elem<T>::pack2(o.x, o.y);
+        pk.y = Elem<T>::pack2(o.z, o.w);
+        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
+      }
+    }
+  }
+}
+
 template <typename T, bool RMS>
 int launch_nv(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out_t,
               int64_t ldo_t, float* out_f, int64_t ldo_f, int M, int D, hipStream_t stream) {
+  if (M <= 2048 && (D >> 2) <= 256 * 8) {   // few rows: one workgroup per row
+    const int nvr = ((D >> 2) + 255) / 256;
+    dim3 g2(M), b2(256);
+#define STLLM_NORMR_CASE(NV)                                                                                     \
+  hipLaunchKernelGGL((norm_row_kernel<T, RMS, NV>), g2, b2, 0, stream, x, ldx, gamma, beta, eps, out_t, ldo_t, \
+                     out_f, ldo_f, M, D)
+    if (nvr <= 1) STLLM_NORMR_CASE(1);
+    else if (nvr <= 2) STLLM_NORMR_CASE(2);
+    else if (nvr <= 4) STLLM_NORMR_CASE(4);
+    else STLLM_NORMR_CASE(8);
+#undef STLLM_NORMR_CASE
+    STLLM_CHECK_LAUNCH(RMS ? "stllm_rmsnorm" : "stllm_layernorm");
+    return STLLM_OK;
+  }
   const int nv = ((D >> 2) + 63) / 64;
   dim3 grid((M + 3) / 4), block(256);
 #define STLLM_NORM_CASE(NV)                                                                                  \
