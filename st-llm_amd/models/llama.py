@@ -8,8 +8,13 @@ Per layer:
     -> [o_proj GEMM + fp32 residual] -> RMSNorm -> [gate/up GEMM + SiLU(gate)*up epilogue]
     -> [down_proj GEMM + fp32 residual]
 
-then the final RMSNorm and lm_head on ALL positions (st_llm.py:122).  The decode loop with a KV cache is
-out of scope this round: ``generate`` below re-runs the prefill per new token.
+then the final RMSNorm and lm_head on ALL positions (st_llm.py:122).
+
+Decode with a KV cache (the step after the prefill in Chat.answer -> generate): the fused QKV
+buffer of every layer IS the cache — ``KVCache`` owns one [B, max_len, 3*D] buffer per layer; the prefill GEMM writes rows
+[0, S) of it through the 2-level row indexing, a decode step writes row `len` (RoPE at that position) and attends over
+rows [0, len] in place: no copies, no re-layout.  Decode reuses the prefill kernels (small-M tiles); GEMV-regime kernels
+are future work.
 """
 import torch
 import torch.nn as nn
@@ -65,6 +70,20 @@ class LlamaDecoderLayer(nn.Module):
                     wdown=pack.linear(m.down_proj.weight, dt))
 
 
+def cfg_max_len(cfg):
+    return int(getattr(cfg, "max_position_embeddings", 2048))
+
+
+class KVCache:
+    """Per-layer fused [q | k | v] rows (compute dtype, k/q in the packed RoPE head layout).  Equal-length sequences only
+    (a clip, or the beams of one clip): right-padded batches would need per-row positions."""
+
+    def __init__(self, n_layers, batch, max_len, hidden, dtype, device):
+        self.max_len, self.batch, self.hidden = max_len, batch, hidden
+        self.qkv = [torch.empty((batch, max_len, 3 * hidden), device=device, dtype=dtype) for _ in range(n_layers)]
+        self.len = 0
+
+
 class LlamaModel(nn.Module):
     def __init__(self, config, device=None):
         super().__init__()
@@ -97,8 +116,8 @@ class LlamaModel(nn.Module):
             self._rope = {S: pack.rope_tables(S, d, self.config.rope_theta, device)}
         return self._rope[S]
 
-    def prefill(self, inputs_embeds, attention_mask=None):
-        """inputs_embeds f32 [B,S,D]; attention_mask [B,S] (1 = token, right-padded) or None.
+    def prefill(self, inputs_embeds, attention_mask=None, cache=None):
+        """inputs_embeds f32 [B,S,D]; attention_mask [B,S] (1 = token, right-padded) or None; cache: KVCache to fill.
         Returns (hidden f32 [B,S,D] after model.norm == hidden_states[-1], hidden in compute dtype [B*S,D])."""
         cfg = self.config
         dt = runtime.compute_dtype()
@@ -116,11 +135,24 @@ class LlamaModel(nn.Module):
             if int(m.sum()) != m.numel():
                 kv_len = m.sum(dim=1).to(torch.int32).to(dev)
         cos, sin = self.rope(S, dev)
-        for pk in layers:
+        if cache is not None:
+            if kv_len is not None:
+                raise NotImplementedError("KV cache needs equal-length sequences")
+            assert cache.batch == B and cache.max_len >= S and cache.qkv[0].dtype == dt
+            cache.len = S
+        for li_, pk in enumerate(layers):
             h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
-            qkv = hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D)
+            if cache is None:
+                qkv = hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D)
+                strides = None
+            else:  # the cache buffer is the GEMM's output: rows (b, s) at b*max_len + s
+                qkv = cache.qkv[li_].view(B * cache.max_len, 3 * D)
+                hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D,
+                         out=qkv, M=B * S, o_rows=(S, cache.max_len * 3 * D))
+                strides = (cache.max_len * 3 * D, 3 * D)
             a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, D=hd,
-                              scale=hd ** -0.5, causal=True, kv_len=kv_len)
+                              scale=hd ** -0.5, causal=True, kv_len=kv_len, q_strides=strides, k_strides=strides,
+                              v_strides=strides)
             hip.gemm(a, pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
             h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
             g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
@@ -128,12 +160,60 @@ class LlamaModel(nn.Module):
         h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
         return h32.view(B, S, D), h16
 
+    def decode_step(self, x_new, cache):
+        """One token per sequence: x_new f32 [B,1,D] (embedding of the token at position cache.len).  Appends its K/V to the
+        cache and returns (hidden f32 [B,1,D] after model.norm, hidden compute-dtype [B,D])."""
+        cfg = self.config
+        dt = runtime.compute_dtype()
+        layers = self.pack(dt)
+        B, _, D = x_new.shape
+        H = cfg.num_attention_heads
+        hd = D // H
+        pos = cache.len
+        assert pos < cache.max_len, "KV cache full"
+        cos, sin = self.rope(cache.max_len, x_new.device)
+        cpos, spos = cos[pos:pos + 1], sin[pos:pos + 1]
+        x = x_new.reshape(B, D).float().clone()
+        ML3 = cache.max_len * 3 * D
+        for li_, pk in enumerate(layers):
+            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
+            row = cache.qkv[li_][:, pos]                                   # [B, 3D] view, row stride max_len*3D
+            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cpos, spos), rope_seq=1, rope_cols=2 * D, out=row)
+            full = cache.qkv[li_].view(B * cache.max_len, 3 * D)
+            a = hip.attention(row[:, :D], full[:, D:2 * D], full[:, 2 * D:], B=B, H=H, Sq=1, Skv=pos + 1, D=hd,
+                              scale=hd ** -0.5, causal=False, q_strides=(ML3, 3 * D), k_strides=(ML3, 3 * D),
+                              v_strides=(ML3, 3 * D))
+            hip.gemm(a, pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+            h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
+            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+        cache.len = pos + 1
+        h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
+        return h32.view(B, 1, D), h16
+
+    def new_cache(self, batch, max_len, device):
+        return KVCache(len(self.layers), batch, max_len, self.config.hidden_size, runtime.compute_dtype(), device)
+
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, use_cache=False,
-                output_hidden_states=False, return_dict=True, **kw):
+                output_hidden_states=False, return_dict=True, past_key_values=None, **kw):
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
-        hidden, h16 = self.prefill(inputs_embeds, attention_mask)
-        out = Output(last_hidden_state=hidden, past_key_values=None,
+        if isinstance(past_key_values, KVCache) and past_key_values.len > 0:   # decode step(s), one token at a time
+            hs = []
+            for t in range(inputs_embeds.shape[1]):
+                hidden, h16 = self.decode_step(inputs_embeds[:, t:t + 1], past_key_values)
+                hs.append(hidden)
+            hidden = torch.cat(hs, dim=1) if len(hs) > 1 else hs[0]
+            out = Output(last_hidden_state=hidden, past_key_values=past_key_values,
+                         hidden_states=(hidden,) if output_hidden_states else None, attentions=None)
+            out._h16 = h16
+            return out
+        cache = None
+        if use_cache:
+            cache = past_key_values if isinstance(past_key_values, KVCache) else \
+                self.new_cache(inputs_embeds.shape[0], min(cfg_max_len(self.config), inputs_embeds.shape[1] + 512), inputs_embeds.device)
+        hidden, h16 = self.prefill(inputs_embeds, attention_mask, cache=cache)
+        out = Output(last_hidden_state=hidden, past_key_values=cache,
                      hidden_states=(hidden,) if output_hidden_states else None, attentions=None)
         out._h16 = h16
         return out

@@ -393,7 +393,10 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
             kwargs.pop("labels", None)
             out = self.model(samples=None, inputs_embeds=inputs_embeds, **kwargs)
             B, S, _ = out.last_hidden_state.shape
-            return Output(loss=None, logits=self.logits_from(out._h16, B, S), past_key_values=None,
+            h16 = out._h16
+            if h16.shape[0] != B * S:   # decode steps return the compute-dtype hidden of the LAST token only
+                S = h16.shape[0] // B
+            return Output(loss=None, logits=self.logits_from(h16, B, S), past_key_values=out.past_key_values,
                           hidden_states=out.hidden_states, attentions=None)
         outputs, loss_pretrain, labels = self.model(samples)
         if outputs is None:
@@ -412,22 +415,36 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
 
     @torch.no_grad()
     def generate(self, inputs_embeds=None, max_new_tokens=16, num_beams=1, do_sample=False, stopping_criteria=None,
-                 attention_mask=None, **unused):
-        """Greedy decoding that re-runs the HIP prefill for every new token (no KV cache this round — the
-        decode loop is SURVEY §8f rank 1).  Returns generated ids [B, n_new] (the prompt has no ids)."""
+                 attention_mask=None, use_cache=True, **unused):
+        """Greedy decoding: HIP prefill of `inputs_embeds` into a KV cache, then one decode step per new token
+        (conversation.py:231-243 hands off to HF generate; beam search / sampling / repetition penalty stay out of scope).
+        Returns the generated ids [B, n_new] (the prompt has no ids)."""
         if num_beams != 1 or do_sample:
             raise NotImplementedError("beam search / sampling stay with HF generate in the reference; greedy only here")
         emb = inputs_embeds.float()
-        B = emb.shape[0]
+        B, S, _ = emb.shape
+        lm = self.model
         out_ids = []
-        for _ in range(max_new_tokens):
-            logits = self.forward(samples=None, inputs_embeds=emb).logits[:, -1]
+        if use_cache:
+            cache = lm.new_cache(B, S + max_new_tokens, emb.device)
+            hidden, h16 = lm.prefill(emb, None, cache=cache)
+            logits = self.logits_from(h16.view(B, S, -1)[:, -1].contiguous(), B, 1)[:, 0]
+        for i in range(max_new_tokens):
+            if not use_cache:
+                logits = self.forward(samples=None, inputs_embeds=emb).logits[:, -1]
             nxt = logits.argmax(dim=-1)
             out_ids.append(nxt)
             ids_so_far = torch.stack(out_ids, dim=1)
             if stopping_criteria is not None and any(sc(ids_so_far, None) for sc in stopping_criteria):
                 break
-            emb = torch.cat([emb, self.model.embed_tokens(nxt.view(B, 1).cpu())], dim=1)
+            if i + 1 == max_new_tokens:
+                break
+            tok = lm.embed_tokens(nxt.view(B, 1).cpu())
+            if use_cache:
+                _, h16 = lm.decode_step(tok, cache)
+                logits = self.logits_from(h16, B, 1)[:, 0]
+            else:
+                emb = torch.cat([emb, tok], dim=1)
         return torch.stack(out_ids, dim=1)
 
     @classmethod

@@ -296,3 +296,39 @@ def test_c1_full_size_vs_reference():
             assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
             assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
     assert res["fp16"][0] <= 0.2 and res["bf16"][0] <= 1.5
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 5e-2)])
+def test_kv_cache_decode_matches_reprefill(mode, tol):
+    """§8f rank 1 (decode loop): prefill into the KV cache + one-token decode steps == re-running the prefill on the
+    extended sequence (B=2 equal-length sequences, 3 Llama layers, full width)."""
+    from stllm_amd import runtime
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    model = fill(STLLMForCausalLM(StllmConfig(num_hidden_layers=3), device="cuda"))
+    B, S, n_new = 2, 37, 4
+    emb = T("input.inputs_embeds", (B, S, 4096), 0.05).cuda()
+    new_ids = torch.tensor([[5, 9, 1234, 77], [31000, 8, 4, 2]])
+    new_emb = model.model.embed_tokens(new_ids)
+    with runtime.use_dtype(mode):
+        lm = model.model
+        cache = lm.new_cache(B, S + n_new, "cuda")
+        _, h16 = lm.prefill(emb, None, cache=cache)
+        step_logits = [model.logits_from(h16.view(B, S, -1)[:, -1].contiguous(), B, 1)[:, 0]]
+        for t in range(n_new):
+            _, h16 = lm.decode_step(new_emb[:, t:t + 1], cache)
+            step_logits.append(model.logits_from(h16, B, 1)[:, 0])
+        full = model(samples=None, inputs_embeds=torch.cat([emb, new_emb], dim=1)).logits
+        # HF-style call surface: use_cache / past_key_values
+        o1 = model(samples=None, inputs_embeds=emb, use_cache=True)
+        o2 = model(samples=None, inputs_embeds=new_emb[:, :1], past_key_values=o1.past_key_values)
+    assert cache.len == S + n_new
+    scale = float(full.abs().max())
+    for t, lg in enumerate(step_logits):
+        err = float((lg - full[:, S - 1 + t]).abs().max())
+        assert err <= tol * scale, f"step {t}: {err:.3e} vs scale {scale:.2f}"
+    assert float((o2.logits[:, -1] - full[:, S]).abs().max()) <= tol * scale
+    with runtime.use_dtype(mode):
+        ids_c = model.generate(inputs_embeds=emb, max_new_tokens=3)
+        ids_n = model.generate(inputs_embeds=emb, max_new_tokens=3, use_cache=False)
+    if mode == "fp32":
+        assert torch.equal(ids_c, ids_n)
