@@ -68,30 +68,28 @@ def cpu_baseline(T, S, budget_s=25.0):
     cores = min(os.cpu_count() or 1, 64)   # more threads than this only adds fork/join overhead at these sizes
     torch.set_num_threads(cores)
     rnd = lambda shp: {k: torch.randn(v) * 0.02 for k, v in shp.items()}
+    NF, VB, QL, LL = 8, 4, 6, 4      # sample: 8 frames x 4/39 ViT blocks, 8 frames x 6/12 Q-Former layers, 4/32 Llama layers
     with torch.no_grad():
-        # ViT: 2 frames through 2 of 39 blocks (+ patch embed)
-        sd = rnd(shapes.vit_shapes(2, "v."))
-        fr = torch.randn(2, 3, 224, 224)
-        O.vit_forward(fr, sd, "v.")  # warm-up (thread pool, allocator)
+        sd = rnd(shapes.vit_shapes(VB, "v."))
+        fr = torch.randn(NF, 3, 224, 224)
+        O.vit_forward(fr[:2], sd, "v.")  # warm-up (thread pool, allocator)
         t0 = time.perf_counter(); O.vit_forward(fr, sd, "v."); t_vit2 = time.perf_counter() - t0
-        vit_per_frame = t_vit2 / 2 / 2 * 39
-        # Q-Former: 2 frames, 2 of 12 layers
-        sd = rnd({**shapes.qformer_shapes(2, False, p="q."), "qt": (1, 32, 768)})
-        enc = torch.randn(2, 257, 1408)
-        O.qformer_forward(sd["qt"].expand(2, -1, -1), enc, sd, "q.")
-        t0 = time.perf_counter(); O.qformer_forward(sd["qt"].expand(2, -1, -1), enc, sd, "q."); t_qf = time.perf_counter() - t0
-        qf_per_frame = t_qf / 2 / 2 * 12
-        # LLM: 1 of 32 layers at the full S (+ lm_head)
-        sd = rnd({k: v for k, v in shapes.llama_shapes(1).items() if "embed" not in k})
+        vit_per_frame = t_vit2 / NF / VB * 39
+        sd = rnd({**shapes.qformer_shapes(QL, False, p="q."), "qt": (1, 32, 768)})
+        enc = torch.randn(NF, 257, 1408)
+        O.qformer_forward(sd["qt"].expand(2, -1, -1), enc[:2], sd, "q.")
+        t0 = time.perf_counter(); O.qformer_forward(sd["qt"].expand(NF, -1, -1), enc, sd, "q."); t_qf = time.perf_counter() - t0
+        qf_per_frame = t_qf / NF / QL * 12
+        sd = rnd({k: v for k, v in shapes.llama_shapes(LL).items() if "embed" not in k})
         x = torch.randn(1, S, 4096) * 0.05
         O.llama_forward(x[:, :64], None, sd)
-        t0 = time.perf_counter(); h = O.llama_forward(x, None, sd); t_l1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); h = O.llama_forward(x, None, sd); t_l1 = (time.perf_counter() - t0) / LL
         t0 = time.perf_counter(); O.lm_logits(h, sd); t_head = time.perf_counter() - t0
     clip_s = T * (vit_per_frame + qf_per_frame) + 32 * t_l1 + t_head
     return {"value": round(T * 32 / clip_s, 3), "unit": "video-tokens/s", "cores": cores, "kind": "port",
             "dtype": "f32",
-            "sample": f"oracle on CPU fp32, {cores} threads: ViT 2 frames x 2/39 blocks ({t_vit2:.2f}s), Q-Former 2 frames x 2/12 "
-                      f"layers ({t_qf:.2f}s), Llama 1/32 layers at S={S} ({t_l1:.2f}s) + lm_head ({t_head:.2f}s); "
+            "sample": f"oracle on CPU fp32, {cores} threads: ViT {NF} frames x {VB}/39 blocks ({t_vit2:.2f}s), Q-Former {NF} frames x "
+                      f"{QL}/12 layers ({t_qf:.2f}s), Llama {LL}/32 layers at S={S} ({t_l1 * LL:.2f}s) + lm_head ({t_head:.2f}s); "
                       f"extrapolated linearly to T={T}, 39/12/32 layers => {clip_s:.1f} s/clip"}
 
 
