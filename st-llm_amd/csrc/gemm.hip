@@ -18,29 +18,11 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
+using namespace sg;
 
-struct GemmParams {
-  const char* A; int64_t lda_b;    // bytes
-  const char* W; int64_t ldw_b;
-  const float* bias;
-  void* out; int64_t ldo;          // elements
-  const float* resid; int64_t ldr;
-  const float* aux0; const float* aux1;
-  const float* frames;
-  int rope_seq, rope_cols;
-  int M, N, K;                     // K in elements (padded)
-  int act, out_is_f32;
-  int tiles_m, tiles_n;
-  char* ws; int64_t ws_bytes; int epoch;   // stream-K workspace: [4 KiB flags | per-workgroup fp32 slabs], launch epoch
-  int debug;                       // ablation bits (env STLLM_GEMM_DEBUG): 1 skip staging, 2 skip MFMA loop, 4 skip copy-out
-  int a_rpb; int64_t a_bs_b;       // A 2-level rows: rows per batch, batch stride (bytes)
-  int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
-};
-
-constexpr int kRowBytes = 128;  // one K panel row
 constexpr bool kUsePrefetchWave = false;  // experimental 5th wave that pulls future K panels into L2
 constexpr int kThreads = kUsePrefetchWave ? 320 : 256;   // 4 MFMA waves (+ 1 L2-prefetch wave)
 constexpr int kPrefetchDist = 6; // panels the prefetch wave runs ahead of the MFMA waves
@@ -55,13 +37,6 @@ template <int BM, int BN> struct Tile {
   static constexpr int kPerCU = (160 * 1024 / kLdsBytes) < (32 / kWavesPerWG) ? (160 * 1024 / kLdsBytes) : (32 / kWavesPerWG);
   static constexpr int kMaxPersistent = kPerCU * 256;
 };
-
-// XCD-aware bijective remap of the linear block id (guide §5: "XCD swizzle must be bijective")
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + k;
-}
 
 // ---- patch-embed implicit-GEMM A loader (eva_vit.py:196-204) ---------------------------------
 // logical element k of patch-row m:  frames[n][c][py*14+dy][px*14+dx],
@@ -93,20 +68,6 @@ __device__ __forceinline__ i32x4 patch_chunk(const float* __restrict__ frames, i
 }
 
 static int g_debug_early() { static int d = -1; if (d < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); d = e ? atoi(e) : 0; } return d; }
-
-constexpr int kGroupM = 8;  // tile rows per L2 locality group
-
-// work id -> (tm, tn): groups of kGroupM tile rows, tm fastest inside a group.  With the XCD remap
-// applied to the PERSISTENT block id, the 64 tiles an XCD runs concurrently form an ~8x8 patch that
-// shares 8 A panels and 8 W panels in that XCD's private L2.
-__device__ __forceinline__ void tile_coords(int w, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int gsz = kGroupM * tiles_n;
-  const int g = w / gsz, rem = w - g * gsz;
-  const int first = g * kGroupM;
-  const int gm = min(kGroupM, tiles_m - first);
-  tn = rem / gm;
-  tm = first + (rem - tn * gm);
-}
 
 template <typename T, int BM, int BN, int EPI, int ACT, bool OF32>
 __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kernel(const GemmParams p) {
@@ -486,7 +447,6 @@ int launch(const GemmParams& p0, hipStream_t stream) {
 // are resident (one per CU: 128-144 KiB LDS each), so the protocol is placement- and order-independent.
 // Flags carry the launch epoch (host counter), so no memset is needed between launches on one stream.
 // =====================================================================================================
-constexpr int kSkFlagBytes = 4096;
 constexpr int kSkMaxSlabWG = 512;
 
 // tile configurations: 128x128 (4 waves, 2 stages, 2 workgroups/CU), 128x256 (8 waves, 3 stages), 256x256 (8 waves, 2 stages)
@@ -501,7 +461,6 @@ template <int BM, int BN> struct SkTile {
   static constexpr int64_t kSlabBytes = (int64_t)BM * BN * 4;
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int BM, int BN, int EPI, int ACT, bool OF32>
 __global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) {
@@ -798,6 +757,9 @@ __global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) 
 }
 
 static int g_sk_epoch = 0;
+}  // namespace
+int stllm_sk_next_epoch() { return ++g_sk_epoch; }   // one epoch counter for every stream-K kernel: they share the flag array
+namespace {
 
 template <typename T, int BM, int BN, int EPI, int ACT = 0, bool OF32 = false>
 int launch_sk(const GemmParams& p0, hipStream_t stream) {
@@ -828,7 +790,7 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
     if (g_debug_early() & 8) fprintf(stderr, "[stllm] gemm_sk<%d,%d> occupancy %d WG/CU x %d CUs\n", BM, BN, per_cu, prop.multiProcessorCount);
   }
   const int grid = total < max_wg ? (int)total : max_wg;
-  p.epoch = ++g_sk_epoch;
+  p.epoch = stllm_sk_next_epoch();
   hipLaunchKernelGGL((gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>), dim3(grid), dim3(SkTile<BM, BN>::NT), lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_gemm(stream-K)");
   {
@@ -848,6 +810,7 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
 // stream-K eligibility + tile: returns 0 (off) | 1 = 128x128 | 2 = 128x256 | 3 = 256x256
 static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): -1 auto, 0 off, 1/2/3 force a tile
 static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
+static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 force the 256x256 phased kernel
 static int sk_choice(const GemmParams& p, int eb) {
   if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
   const int mode = g_sk_mode;
@@ -897,8 +860,23 @@ int dispatch_store(const GemmParams& p, hipStream_t stream) {
   return STLLM_ERR_UNSUPPORTED;
 }
 
+// 256x256 phased stream-K kernel (gemm_p8.hip): 16-bit dtypes, needs the stream-K workspace
+static bool p8_wanted(const GemmParams& p) {
+  if (g_p8_mode == -2) { const char* e = getenv("STLLM_GEMM_P8"); g_p8_mode = e ? atoi(e) : -1; }
+  if (g_p8_mode == 0 || p.ws == nullptr) return false;
+  if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
+  if (g_p8_mode == 1) return true;
+  return false;
+}
+
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
+  if constexpr (!Elem<T>::kIsF32) {
+    if (a->epilogue != STLLM_EPI_PATCH && p8_wanted(p)) {
+      const int rc = stllm_gemm_p8_launch(a->dtype, a->epilogue, p, stream);
+      if (rc != STLLM_ERR_UNSUPPORTED) return rc;
+    }
+  }
   switch (a->epilogue) {
     case STLLM_EPI_STORE: return dispatch_store<T>(p, stream);
     case STLLM_EPI_RESID: return dispatch_tile<T, STLLM_EPI_RESID>(p, stream);
@@ -971,6 +949,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!key) return STLLM_ERR_BAD_SHAPE;
   if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;
 }

@@ -1,0 +1,57 @@
+// Shared between the GEMM translation units (gemm.hip: 128x128 persistent + stream-K kernels, gemm_p8.hip: the
+// 256x256 phased stream-K kernel).
+#pragma once
+#include "common.h"
+
+namespace sg {
+
+struct GemmParams {
+  const char* A; int64_t lda_b;    // bytes
+  const char* W; int64_t ldw_b;
+  const float* bias;
+  void* out; int64_t ldo;          // elements
+  const float* resid; int64_t ldr;
+  const float* aux0; const float* aux1;
+  const float* frames;
+  int rope_seq, rope_cols;
+  int M, N, K;                     // K in elements (padded)
+  int act, out_is_f32;
+  int tiles_m, tiles_n;
+  char* ws; int64_t ws_bytes; int epoch;   // stream-K workspace: [4 KiB flags | per-workgroup fp32 slabs], launch epoch
+  int debug;                       // ablation bits (env STLLM_GEMM_DEBUG): 1 skip staging, 2 skip MFMA loop, 4 skip copy-out
+  int a_rpb; int64_t a_bs_b;       // A 2-level rows: rows per batch, batch stride (bytes)
+  int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
+};
+
+constexpr int kRowBytes = 128;  // one K panel row
+// XCD-aware bijective remap of the linear block id (guide §5: "XCD swizzle must be bijective")
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+constexpr int kGroupM = 8;  // tile rows per L2 locality group
+
+// work id -> (tm, tn): groups of kGroupM tile rows, tm fastest inside a group.  With the XCD remap
+// applied to the PERSISTENT block id, the 64 tiles an XCD runs concurrently form an ~8x8 patch that
+// shares 8 A panels and 8 W panels in that XCD's private L2.
+__device__ __forceinline__ void tile_coords(int w, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int gsz = kGroupM * tiles_n;
+  const int g = w / gsz, rem = w - g * gsz;
+  const int first = g * kGroupM;
+  const int gm = min(kGroupM, tiles_m - first);
+  tn = rem / gm;
+  tm = first + (rem - tn * gm);
+}
+
+constexpr int kSkFlagBytes = 4096;   // stream-K workspace: [flags | per-workgroup fp32 slabs]
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+}  // namespace sg
+
+// 256x256 phased stream-K kernel (gemm_p8.hip); 16-bit dtypes only, every epilogue except PATCH.
+// Returns STLLM_OK or an error code; `dtype` is STLLM_BF16 / STLLM_F16.
+int stllm_sk_next_epoch();   // gemm.hip: launch epoch shared by all stream-K kernels (one flag array)
+int stllm_gemm_p8_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream);
