@@ -810,7 +810,7 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
 // stream-K eligibility + tile: returns 0 (off) | 1 = 128x128 | 2 = 128x256 | 3 = 256x256
 static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): -1 auto, 0 off, 1/2/3 force a tile
 static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
-static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 force the 256x256 phased kernel
+static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 phased kernel (3 / 4: force 192 / 256 rows)
 static int sk_choice(const GemmParams& p, int eb) {
   if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
   const int mode = g_sk_mode;
@@ -865,7 +865,7 @@ static bool p8_wanted(const GemmParams& p) {
   if (g_p8_mode == -2) { const char* e = getenv("STLLM_GEMM_P8"); g_p8_mode = e ? atoi(e) : -1; }
   if (g_p8_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
-  if (g_p8_mode == 1) return true;
+  if (g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4) return true;   // 1: cost model picks MIW; 3 / 4: forced
   return false;
 }
 
@@ -873,7 +873,11 @@ template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
     if (a->epilogue != STLLM_EPI_PATCH && p8_wanted(p)) {
-      const int rc = stllm_gemm_p8_launch(a->dtype, a->epilogue, p, stream);
+      int miw = 4;
+      (void)stllm_gemm_p8_estimate_us(p.M, p.N, p.K, &miw);
+      if (g_p8_mode == 3 || g_p8_mode == 4) miw = g_p8_mode;
+      const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_p8_launch_bf16(a->epilogue, miw, p, stream)
+                                                    : stllm_gemm_p8_launch_f16(a->epilogue, miw, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
     }
   }

@@ -1,5 +1,5 @@
-// Shared between the GEMM translation units (gemm.hip: 128x128 persistent + stream-K kernels, gemm_p8.hip: the
-// 256x256 phased stream-K kernel).
+// Shared between the GEMM translation units (gemm.hip: 128x128 persistent + stream-K kernels, gemm_p8_*.hip: the
+// phased kernel).
 #pragma once
 #include "common.h"
 
@@ -21,6 +21,7 @@ struct GemmParams {
   int debug;                       // ablation bits (env STLLM_GEMM_DEBUG): 1 skip staging, 2 skip MFMA loop, 4 skip copy-out
   int a_rpb; int64_t a_bs_b;       // A 2-level rows: rows per batch, batch stride (bytes)
   int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
+  int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
 };
 
 constexpr int kRowBytes = 128;  // one K panel row
@@ -51,7 +52,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 }  // namespace sg
 
-// 256x256 phased stream-K kernel (gemm_p8.hip); 16-bit dtypes only, every epilogue except PATCH.
-// Returns STLLM_OK or an error code; `dtype` is STLLM_BF16 / STLLM_F16.
-int stllm_sk_next_epoch();   // gemm.hip: launch epoch shared by all stream-K kernels (one flag array)
-int stllm_gemm_p8_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream);
+// (64*MIW) x 256 phased kernel (gemm_p8.inc, one TU per 16-bit dtype); every epilogue except PATCH.
+// Returns STLLM_OK, STLLM_ERR_UNSUPPORTED (caller falls back to the 128x128 kernels) or an error code.
+int stllm_sk_next_epoch();   // gemm.hip: launch epoch shared by all kernels that use the workspace flag array
+int stllm_gemm_p8_launch_bf16(int epilogue, int miw, const sg::GemmParams& p, hipStream_t stream);
+int stllm_gemm_p8_launch_f16(int epilogue, int miw, const sg::GemmParams& p, hipStream_t stream);
+float stllm_gemm_p8_estimate_us(int M, int N, int K, int* miw);   // cost model of the schedule; picks MIW (4: 256 rows, 3: 192 rows)

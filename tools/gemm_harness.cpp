@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 20;
   const int only = argc > 2 ? atoi(argv[2]) : -1;
   const int trace = argc > 3 ? atoi(argv[3]) : 0;
+  const int p8opt = argc > 4 ? atoi(argv[4]) : 1;   // 1: cost model picks the tile height, 3 / 4: force 192 / 256 rows
   std::vector<Case> cases = {
       {"tiny_store", 256, 256, 128, STLLM_EPI_STORE, 0, 0},
       {"edge_store", 300, 384, 192, STLLM_EPI_STORE, 0, 0},
@@ -89,14 +90,16 @@ int main(int argc, char** argv) {
     for (auto& v : hb) v = urand() * 0.5f;
     for (auto& v : hres) v = urand();
     for (int i = 0; i < 576 * 64; ++i) { hcos[i] = cosf(0.37f * i); hsin[i] = sinf(0.37f * i); }
-    void *dA, *dW, *dout0, *dout1, *dfirst;
+    void *dA, *dA2, *dW, *dout0, *dout1, *dfirst;
     float *db, *dres, *dcos, *dsin;
-    CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2));
+    CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dA2, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2));
     CK(hipMalloc(&db, N * 4)); CK(hipMalloc(&dres, hres.size() * 4));
     CK(hipMalloc(&dcos, hcos.size() * 4)); CK(hipMalloc(&dsin, hsin.size() * 4));
     const size_t obytes = (size_t)M * No * oes;
     CK(hipMalloc(&dout0, obytes)); CK(hipMalloc(&dout1, obytes)); CK(hipMalloc(&dfirst, obytes));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    for (auto& v : hA) v = f2bf(urand());   // a second operand set: alternating launches expose stale slab reads
+    CK(hipMemcpy(dA2, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dres, hres.data(), hres.size() * 4, hipMemcpyHostToDevice));
@@ -111,7 +114,7 @@ int main(int argc, char** argv) {
     a.M = M; a.N = N; a.K = K; a.workspace = ws; a.workspace_bytes = ws_bytes;
 
     auto run = [&](int p8, void* out, float* us, const char** kname) -> int {
-      stllm_set_option("gemm_p8", p8);
+      stllm_set_option("gemm_p8", p8 ? p8opt : 0);
       stllm_set_option("gemm_sk", p8 ? -1 : 0);
       a.out = out;
       CK(hipMemsetAsync(out, 0xff, obytes, st));
@@ -119,23 +122,33 @@ int main(int argc, char** argv) {
       if (rc != STLLM_OK) { printf("  stllm_gemm rc=%d: %s\n", rc, stllm_last_error()); return rc; }
       *kname = stllm_last_kernel();
       CK(hipStreamSynchronize(st));
-      if (p8) {   // race screen: all repeats bit-identical to the first
-        CK(hipMemcpy(dfirst, out, obytes, hipMemcpyDeviceToDevice));
-        std::vector<char> h0(obytes), h1(obytes);
-        CK(hipMemcpy(h0.data(), dfirst, obytes, hipMemcpyDeviceToHost));
-        for (int r = 0; r < 6; ++r) {
+      if (p8) {   // race / staleness screen: alternate two operand sets; every repeat bit-identical to its first result
+        std::vector<char> h0(obytes), h2(obytes), h1(obytes);
+        CK(hipMemcpy(h0.data(), out, obytes, hipMemcpyDeviceToHost));
+        a.A = dA2;
+        stllm_gemm(&a, st);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(h2.data(), out, obytes, hipMemcpyDeviceToHost));
+        for (int r = 0; r < 8; ++r) {
+          a.A = (r & 1) ? dA2 : dA;
           CK(hipMemsetAsync(out, 0xff, obytes, st));
           stllm_gemm(&a, st);
           CK(hipStreamSynchronize(st));
           CK(hipMemcpy(h1.data(), out, obytes, hipMemcpyDeviceToHost));
-          if (memcmp(h0.data(), h1.data(), obytes) != 0) {
+          const std::vector<char>& ref = (r & 1) ? h2 : h0;
+          if (memcmp(ref.data(), h1.data(), obytes) != 0) {
             size_t nd = 0, first = 0;
-            for (size_t i = 0; i < obytes; ++i) if (h0[i] != h1[i]) { if (!nd) first = i; ++nd; }
+            for (size_t i = 0; i < obytes; ++i) if (ref[i] != h1[i]) { if (!nd) first = i; ++nd; }
             printf("  RACE: repeat %d differs from the first run in %zu bytes (first at element %zu = row %zu col %zu)\n", r, nd,
                    first / oes, first / oes / No, first / oes % No);
+            a.A = dA;
             return -100;
           }
         }
+        a.A = dA;
+        CK(hipMemsetAsync(out, 0xff, obytes, st));
+        stllm_gemm(&a, st);
+        CK(hipStreamSynchronize(st));
       }
       CK(hipEventRecord(e0, st));
       for (int r = 0; r < reps; ++r) stllm_gemm(&a, st);
@@ -172,7 +185,7 @@ int main(int argc, char** argv) {
       const size_t dbytes = 256 * 64 * 8;
       CK(hipMalloc(&ddbg, dbytes));
       CK(hipMemset(ddbg, 0, dbytes));
-      stllm_set_option("gemm_p8", 1);
+      stllm_set_option("gemm_p8", p8opt);
       stllm_set_option("gemm_debug", 16);
       a.frames = (const float*)ddbg;
       a.out = dout1;
@@ -222,7 +235,7 @@ int main(int argc, char** argv) {
     printf(" %s\n", (rc0 || rc1 || nbad) ? "FAIL" : "ok");
     fflush(stdout);
     if (rc0 || rc1 || nbad) ++bad;
-    hipFree(dA); hipFree(dW); hipFree(db); hipFree(dres); hipFree(dcos); hipFree(dsin); hipFree(dout0); hipFree(dout1); hipFree(dfirst);
+    hipFree(dA); hipFree(dA2); hipFree(dW); hipFree(db); hipFree(dres); hipFree(dcos); hipFree(dsin); hipFree(dout0); hipFree(dout1); hipFree(dfirst);
     if (rc1 == -100) break;
   }
   printf("%s\n", bad ? "HARNESS FAIL" : "HARNESS OK");
