@@ -860,22 +860,31 @@ int dispatch_store(const GemmParams& p, hipStream_t stream) {
   return STLLM_ERR_UNSUPPORTED;
 }
 
-// 256x256 phased stream-K kernel (gemm_p8.hip): 16-bit dtypes, needs the stream-K workspace
-static bool p8_wanted(const GemmParams& p) {
+// Phased kernel (gemm_p8.inc): 16-bit dtypes, needs the workspace.  mode 1 / 3 / 4: always (cost model / 192 / 256 rows);
+// auto: when its cost model beats the estimate for the 128x128 kernels by a margin (both calibrated on MI355X, see
+// profiles/r01_gemm_p8.md; a wrong guess near the margin costs a few percent either way).
+static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   if (g_p8_mode == -2) { const char* e = getenv("STLLM_GEMM_P8"); g_p8_mode = e ? atoi(e) : -1; }
   if (g_p8_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
-  if (g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4) return true;   // 1: cost model picks MIW; 3 / 4: forced
-  return false;
+  const float est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, miw);
+  if (g_p8_mode == 3 || g_p8_mode == 4) { *miw = g_p8_mode; return true; }
+  if (g_p8_mode == 1) return true;
+  const int nk = p.K / 64;
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
+  float old_us;
+  if (t128 < 192) old_us = 5.0f + nk * 0.55f;                       // 64x64 tiles, 4 workgroups per CU
+  else old_us = 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
+  return est < 0.93f * old_us;
 }
 
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
-    if (a->epilogue != STLLM_EPI_PATCH && p8_wanted(p)) {
-      int miw = 4;
-      (void)stllm_gemm_p8_estimate_us(p.M, p.N, p.K, &miw);
-      if (g_p8_mode == 3 || g_p8_mode == 4) miw = g_p8_mode;
+    int miw = 4;
+    const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
+                    : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;
+    if (a->epilogue != STLLM_EPI_PATCH && p8_wanted(p, heavy, &miw)) {
       const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_p8_launch_bf16(a->epilogue, miw, p, stream)
                                                     : stllm_gemm_p8_launch_f16(a->epilogue, miw, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;

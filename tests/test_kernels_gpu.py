@@ -255,6 +255,103 @@ def test_gemm_stream_k_swiglu_rope(hip, dtype, bm):
         hip.set_option("gemm_sk", -1)
 
 
+P8_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (576, 1536, 11008 // 2), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7),
+             (2100, 2944, 256)]
+
+
+@pytest.mark.parametrize("miw", [3, 4])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", P8_SHAPES)
+def test_gemm_phased(hip, dtype, miw, M, N, K):
+    """phased kernel forced on (192- and 256-row tiles): data-parallel rounds, K-split remainder groups with the
+    reduce-scatter exchange, M / N tails, fp32 / GELU / residual epilogues, epoch flags, determinism."""
+    hip.set_option("gemm_p8", miw)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        a2, a264 = rnd("a_other", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        ref2 = a264 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_p8_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},{miw},")
+        check(out, ref, ACC_TOL[dtype], "p8 store f32")
+        # alternate operands: a stale partial slab from the previous launch would show up here
+        for rep in range(3):
+            check(hip.gemm(a2, w, dtype=dtype, bias=b.cuda(), out_f32=True), ref2, ACC_TOL[dtype], f"p8 store f32 (other operand, rep {rep})")
+            o1 = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+            assert torch.equal(o1, out), "p8: not bit-identical across launches"
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "p8 gelu T")
+        check(hip.gemm(a, w, dtype=dtype), a64 @ w64.t(), OUT_TOL[dtype], "p8 store T, no bias")
+        x = T("x", (M, N), 2.0)
+        xd = x.cuda()
+        for rep in range(2):
+            hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+        check(xd, x.double() + 2 * ref, ACC_TOL[dtype], "p8 resid x2")
+    finally:
+        hip.set_option("gemm_p8", -1)
+
+
+@pytest.mark.parametrize("miw", [3, 4])
+def test_gemm_phased_swiglu_rope_rows(hip, miw):
+    from stllm_amd import pack
+    dtype = "bf16"
+    hip.set_option("gemm_p8", miw)
+    try:
+        M, K, I = 333, 1024, 1024 + 128 * 3
+        a, a64 = rnd("a", (M, K), dtype)
+        wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+        wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+        out = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
+        assert "gemm_p8_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(out, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "p8 swiglu")
+        B, S, H, D = 2, 150, 4, 128
+        a, a64 = rnd("a2", (B * S, K), dtype)
+        wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+        wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+        wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+        cos, sin = pack.rope_tables(S)
+        qkv = hip.gemm(a, pack.llama_qkv(wq, wk, wv, dtype, n_heads=H), dtype=dtype, epilogue=hip.EPI_ROPE,
+                       rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D).double().cpu().view(B, S, 3, H, D)
+        assert "gemm_p8_kernel" in hip.lib().stllm_last_kernel().decode()
+        c, s = O.rope_tables(S, D)
+        q = (a64 @ wq64.t()).view(B, S, H, D).transpose(1, 2)
+        k = (a64 @ wk64.t()).view(B, S, H, D).transpose(1, 2)
+        q = q * c.double() + O._rotate_half(q) * s.double()
+        k = k * c.double() + O._rotate_half(k) * s.double()
+        perm = pack.rope_head_perm(1)
+        check(qkv[:, :, 0].transpose(1, 2), q[..., perm], OUT_TOL[dtype], "p8 q rope")
+        check(qkv[:, :, 1].transpose(1, 2), k[..., perm], OUT_TOL[dtype], "p8 k rope")
+        check(qkv[:, :, 2], (a64 @ wv64.t()).view(B, S, H, D), OUT_TOL[dtype], "p8 v")
+        # 2-level row indexing (Q-Former style row groups) through the phased kernel
+        N_, S2, Q, C, Nout = 5, 44, 32, 768, 256
+        buf, buf64 = rnd("buf", (N_ * S2, C), dtype)
+        w, w64 = rnd("w2", (Nout, C), dtype, 0.05)
+        outb = torch.zeros((N_ * S2, Nout), device="cuda", dtype=torch.float32)
+        hip.gemm(buf, w, dtype=dtype, out=outb, out_f32=True, M=N_ * Q, a_rows=(Q, S2 * C), o_rows=(Q, S2 * Nout))
+        assert "gemm_p8_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(outb.view(N_, S2, Nout)[:, :Q].reshape(-1, Nout), buf64.view(N_, S2, C)[:, :Q].reshape(-1, C) @ w64.t(), ACC_TOL[dtype], "p8 query rows")
+        assert float(outb.view(N_, S2, Nout)[:, Q:].abs().max()) == 0.0
+    finally:
+        hip.set_option("gemm_p8", -1)
+
+
+def test_gemm_phased_auto_dispatch(hip):
+    """the cost model sends the long-K / few-row-tile prefill shapes to the phased kernel and keeps small problems on
+    the 128x128 kernels"""
+    dtype = "bf16"
+    a, a64 = rnd("a", (576, 11008), dtype, 0.5)
+    w, w64 = rnd("w", (4096, 11008), dtype, 0.05)
+    x = torch.zeros((576, 4096), device="cuda")
+    hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, resid=x)
+    assert hip.lib().stllm_last_kernel().decode().startswith("gemm_p8_kernel<bf16_t,3,RESID")
+    check(x, a64 @ w64.t(), ACC_TOL[dtype], "auto p8 resid")
+    a, a64 = rnd("a3", (512, 768), dtype, 0.5)
+    w, w64 = rnd("w3", (768, 768), dtype, 0.05)
+    hip.gemm(a, w, dtype=dtype)
+    assert hip.lib().stllm_last_kernel().decode().startswith("gemm_kernel<")
+
+
 def test_gemm_rejects_bad_shapes(hip):
     a = torch.zeros((8, 100), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
