@@ -95,13 +95,17 @@ typedef struct {
    * (Qformer.py:430-462 slices hidden states by query_length). */
   int a_rows_per_batch; int64_t a_batch_stride;
   int o_rows_per_batch; int64_t o_batch_stride;
-  /* optional scratch for the stream-K kernel (large problems): >= stllm_gemm_workspace_bytes() bytes of device
+  /* optional scratch for the phased / stream-K kernels (large problems): >= stllm_gemm_workspace_bytes() bytes of device
    * memory, 16-byte aligned, private to the launch stream (launches on one stream may share it).  NULL => the
    * small-tile kernel is used for every shape.  Contents need no initialisation beyond one memset at allocation. */
   void* workspace; int64_t workspace_bytes;
 } stllm_gemm_args;
 int64_t stllm_gemm_workspace_bytes(void);
-/* tuning / test hooks: "gemm_sk" = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256) stream-K tile, "gemm_debug" = ablation bits */
+/* tuning / test hooks:
+ *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
+ *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
+ *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
+ *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
 int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);
 

@@ -870,6 +870,7 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   const float est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, miw);
   if (g_p8_mode == 3 || g_p8_mode == 4) { *miw = g_p8_mode; return true; }
   if (g_p8_mode == 1) return true;
+  if (g_sk_mode >= 1) return false;   // a forced stream-K tile (tests / experiments) wins over the automatic choice
   const int nk = p.K / 64;
   const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
   float old_us;

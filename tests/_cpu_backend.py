@@ -93,9 +93,11 @@ def rmsnorm(x, gamma, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want
 
 def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, out=None, q_strides=None, k_strides=None,
               v_strides=None):
-    def heads(t, S):
-        return t[:, : H * D].float().reshape(B, S, H, D).transpose(1, 2) if t.shape[0] == B * S else None
-    qh, kh, vh = heads(q, Sq), heads(k, Skv), heads(v, Skv)
+    def heads(t, S, strides):
+        """element (b, s, h, d) lives at t.flat[b * batch_stride + s * row_stride + h * D + d] (include/stllm_hip.h)"""
+        bs, rs = strides if strides is not None else (S * t.stride(0), t.stride(0))
+        return torch.as_strided(t, (B, S, H, D), (bs, rs, D, 1), t.storage_offset()).float().transpose(1, 2)
+    qh, kh, vh = heads(q, Sq, q_strides), heads(k, Skv, k_strides), heads(v, Skv, v_strides)
     s = (qh @ kh.transpose(-1, -2)) * scale
     if causal:
         s = s.masked_fill(torch.ones(Sq, Skv).triu(1).bool(), float("-inf"))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run ONE GEMM shape a few times (for rocprofv3 --pmc passes).  python tools/gemm_one.py M N K [iters] [epi]"""
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc passes).  python tools/gemm_one.py M N K [iters] [store|resid|gelu]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +10,12 @@ epi = sys.argv[5] if len(sys.argv) > 5 else "store"
 A = (torch.rand(M, K, device="cuda") * 2 - 1).to(torch.bfloat16)
 W = ((torch.rand(N, K, device="cuda") * 2 - 1) * 0.05).to(torch.bfloat16)
 x = torch.rand(M, N, device="cuda")
+b = torch.rand(N, device="cuda")
 for _ in range(iters):
     if epi == "resid":
-        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_RESID, resid=x)
+        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_RESID, bias=b, resid=x)
+    elif epi == "gelu":
+        hip.gemm(A, W, dtype="bf16", bias=b, act=hip.ACT_GELU)
     else:
         hip.gemm(A, W, dtype="bf16")
 torch.cuda.synchronize()
