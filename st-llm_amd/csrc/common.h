@@ -136,6 +136,28 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// GELU for 16-bit OUTPUTS of the phased GEMM epilogue: Phi(x) = 0.5 + x * P(x^2) on |x| <= 4.3 with a degree-8 polynomial
+// fitted to 0.5*erf(x/sqrt2)/x: |Phi error| <= 1.3e-5, |GELU error| <= 5.5e-5 absolute (below the fp16 / bf16 rounding of any
+// result of magnitude >= 0.1; in the far negative tail, where GELU itself is < 1e-3, the relative error reaches 1e-2), exact 0
+// below -4.3.
+// 14 full-rate VALU ops instead of ~12 + two quarter-rate transcendentals: the GELU pass of one 192x256 tile drops from
+// ~7 us to ~3.5 us of pure VALU time that nothing else can hide (profiles/r01_gemm_p8.md).
+__device__ __forceinline__ float gelu_poly16(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -4.3f, 4.3f);
+  const float t = xc * xc;
+  float p = 5.1581142135326274e-11f;
+  p = fmaf(p, t, -5.033940375653856e-09f);
+  p = fmaf(p, t, 2.1685210072064365e-07f);
+  p = fmaf(p, t, -5.490918738360051e-06f);
+  p = fmaf(p, t, 9.222461812896654e-05f);
+  p = fmaf(p, t, -0.00110264727845788f);
+  p = fmaf(p, t, 0.009800615720450878f);
+  p = fmaf(p, t, -0.06632684171199799f);
+  p = fmaf(p, t, 0.3988965153694153f);
+  float phi = fmaf(xc, p, 0.5f);
+  phi = x < -4.3f ? 0.0f : phi;
+  return x * phi;
+}
 __device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
