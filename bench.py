@@ -166,6 +166,8 @@ def main():
     sync()
     dt_s = time.perf_counter() - t0
     hip.set_profiler(None)
+    if not hip.gemm_workspace_ok(device):   # a split-K exchange gave up waiting for a peer workgroup: the numbers would be meaningless
+        raise RuntimeError(hip.lib().stllm_last_error().decode())
     t = torch.tensor([dt_s], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -101,6 +101,10 @@ typedef struct {
   void* workspace; int64_t workspace_bytes;
 } stllm_gemm_args;
 int64_t stllm_gemm_workspace_bytes(void);
+/* Synchronises `stream` and returns 0 when no GEMM launch that used `workspace` ever gave up waiting for a peer workgroup
+ * (the split-K exchanges poll with a bound instead of hanging the GPU when not all workgroups are resident, e.g. on a
+ * GPU shared with another process), non-zero otherwise (sticky; stllm_last_error() explains). */
+int stllm_gemm_workspace_status(const void* workspace, void* stream);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)

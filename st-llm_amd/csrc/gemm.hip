@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -597,9 +598,13 @@ __global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) 
       if (wave == 0) {  // one wave polls, relaxed; bounded so that a broken run ends instead of hanging the GPU
         for (int q = 0; q < ncontrib; ++q) {
           unsigned spins = 0;
-          while (__hip_atomic_load(&flags[g + 1 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.epoch &&
-                 ++spins < (1u << 22))
+          while (__hip_atomic_load(&flags[g + 1 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.epoch) {
+            if (++spins >= (1u << 22)) {   // contributor never showed up: flag it (stllm_gemm_workspace_status), never hang
+              if (lane == 0) __hip_atomic_fetch_or(&flags[kSkErrWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
             __builtin_amdgcn_s_sleep(8);
+          }
         }
         if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
@@ -756,7 +761,7 @@ __global__ __launch_bounds__(2 * BN, 2) void gemm_sk_kernel(const GemmParams p) 
 #undef STLLM_BAR
 }
 
-static int g_sk_epoch = 0;
+static std::atomic<int> g_sk_epoch{0};
 }  // namespace
 int stllm_sk_next_epoch() { return ++g_sk_epoch; }   // one epoch counter for every stream-K kernel: they share the flag array
 namespace {
@@ -955,6 +960,19 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
     case STLLM_F16: return dispatch_epi<f16_t>(a, p, stream);
     default: return dispatch_epi<float>(a, p, stream);
   }
+}
+
+extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_) {
+  if (!workspace) return 0;
+  unsigned w = 0;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (hipMemcpyAsync(&w, reinterpret_cast<const unsigned*>(workspace) + kSkErrWord, sizeof(w), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess) {
+    stllm_set_error("stllm_gemm_workspace_status: cannot read the workspace");
+    return STLLM_ERR_HIP;
+  }
+  if (w) stllm_set_error("stllm_gemm: a split-K workgroup timed out waiting for a peer (flags 0x%x): results of that launch are invalid", w);
+  return (int)w;
 }
 
 extern "C" int64_t stllm_gemm_workspace_bytes(void) { return kSkFlagBytes + (int64_t)256 * 256 * 256 * 4; }  // = 512 slabs of 128x128 too

@@ -46,7 +46,8 @@ __device__ __forceinline__ void tile_coords(int w, int tiles_m, int tiles_n, int
   tm = first + (rem - tn * gm);
 }
 
-constexpr int kSkFlagBytes = 4096;   // stream-K workspace: [flags | per-workgroup fp32 slabs]
+constexpr int kSkFlagBytes = 4096;   // workspace: [1024 flag words | per-workgroup fp32 slabs]
+constexpr int kSkErrWord = 1000;     // flag word set by a kernel whose bounded poll for a peer workgroup expired (stllm_gemm_workspace_status)
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

@@ -21,7 +21,7 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_set_option"]
+           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_set_option"]
 
 
 def torch_dtype(d):
@@ -78,6 +78,7 @@ def lib():
             getattr(L, n).restype = c_int
         L.stllm_gemm_workspace_bytes.restype = c_int64
         L.stllm_set_option.argtypes = [c_char_p, c_int]
+        L.stllm_gemm_workspace_status.argtypes = [c_void_p, c_void_p]
         _lib = L
     return _lib
 
@@ -117,6 +118,15 @@ def gemm_workspace(device):
         ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{key}")
         _workspaces[key] = ws
     return ws
+
+
+def gemm_workspace_ok(device=None):
+    """Synchronises and returns True when no split-K GEMM exchange on this device ever timed out (see stllm_hip.h)."""
+    key = torch.cuda.current_device() if device is None else torch.device(device).index
+    ws = _workspaces.get(key)
+    if ws is None:
+        return True
+    return int(lib().stllm_gemm_workspace_status(_p(ws), _stream())) == 0
 
 
 class GemmProfiler:

@@ -37,4 +37,18 @@ def run(verbose=True):
         if verbose:
             print(f"[smoke] {mode}: logits max-abs err {err:.3e} (abs-max {scale:.2f}), loss err {lerr:.2e}")
         assert err <= tol * max(1.0, scale), f"smoke {mode}: logits err {err} > {tol}"
+    # the tiny model's GEMMs stay on the 128x128 kernels: push one small problem through the phased split-K kernel as well
+    from stllm_amd import hip
+    a = synth.normal_(torch.empty(300, 256), "smoke.a", 0, 1.0).to(torch.bfloat16).cuda()
+    w = synth.normal_(torch.empty(512, 256), "smoke.w", 0, 0.05).to(torch.bfloat16).cuda()
+    hip.set_option("gemm_p8", 3)
+    try:
+        got = hip.gemm(a, w, dtype="bf16", out_f32=True)
+    finally:
+        hip.set_option("gemm_p8", -1)
+    assert hip.lib().stllm_last_kernel().decode().startswith("gemm_p8_kernel<")
+    gerr = (got.cpu() - a.float().cpu() @ w.float().cpu().t()).abs().max().item()
+    if verbose:
+        print(f"[smoke] phased GEMM 300x512x256 (K split across one XCD's workgroups): max-abs err {gerr:.2e}")
+    assert gerr < 1e-4 and hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
     return True

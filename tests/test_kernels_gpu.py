@@ -350,6 +350,7 @@ def test_gemm_phased_auto_dispatch(hip):
     w, w64 = rnd("w3", (768, 768), dtype, 0.05)
     hip.gemm(a, w, dtype=dtype)
     assert hip.lib().stllm_last_kernel().decode().startswith("gemm_kernel<")
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()   # no split-K exchange of this process ever timed out
 
 
 def test_gemm_rejects_bad_shapes(hip):
