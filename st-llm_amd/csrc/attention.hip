@@ -201,7 +201,10 @@ __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) 
 // 96 dims), one barrier, then every wave walks all key tiles for its own 32 query rows with NO further barriers: waves
 // run decoupled, so LDS/MFMA/VALU latencies of one wave hide under the others (PMC on the tiled kernel: 55 % of wave
 // time parked at barriers/waits).  One workgroup per (batch, head): 16 frames x 16 heads = 256 workgroups = one per CU.
-template <typename T, int DP, int SKV_MAX>
+// KS2 = 2 / 4: every query tile is worked on by KS2 waves that take every KS2-th 32-key tile (the causal prefill has few, long
+// query tiles: 32 heads x 18 tiles walk up to 18 key tiles each — the serial walk, not the FLOPs, sets the time); the
+// partial (m, l, O) states are merged through LDS at the end.
+template <typename T, int DP, int SKV_MAX, int KS2 = 1>
 __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) {
   // SKV_MAX = keys staged per pass (the "window").  Keys beyond one window are handled by further passes (one pair of
   // barriers per window instead of per 32-key tile); blockIdx.x selects a chunk of blockDim.x/64 query tiles.
@@ -213,7 +216,8 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
   char* k_lds = smem;
   char* v_lds = smem + SKV_MAX * KPITCH;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, nwaves = (blockDim.x >> 6) / KS2;
+  const int wave = wave_all % nwaves, kpar = wave_all / nwaves;   // query tile within the chunk, key-tile parity (KS2 = 2)
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int D = p.D;
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
     int t_end = n_tiles;
     if (p.causal) t_end = min(n_tiles, qt + 1 - (win0 >> 5));   // tiles up to this wave's diagonal
     for (int t = 0; t < t_end; ++t) {
+      if (KS2 > 1 && (((win0 >> 5) + t) & (KS2 - 1)) != kpar) continue;   // the partner wave takes this key tile
       const int kv0 = win0 + t * 32;   // global key index of the tile; LDS rows are window-relative
       f32x16 s;
 #pragma unroll
@@ -331,6 +336,36 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
     }
     }
   }
+  if constexpr (KS2 > 1) {
+    // merge the two key-parity partials of every query tile: parity 1 parks (m, l, O) in LDS (the K/V windows are dead),
+    // parity 0 combines:  m = max(m0, m1);  O = O0 * 2^((m0-m)*c) + O1 * 2^((m1-m)*c);  l likewise
+    float* mbuf = reinterpret_cast<float*>(smem);
+    for (int pp = 1; pp < KS2; ++pp) {   // one partner at a time: the merge buffer has to fit the (dead) K/V windows
+      __syncthreads();
+      if (kpar == pp) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] = o[i][r];
+        mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane] = m_run;
+        mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane] = l_run;
+      }
+      __syncthreads();
+      if (kpar == 0) {
+        const float m1 = mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane];
+        const float l1 = mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.scale_log2), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.scale_log2);
+        l_run = l_run * a0 + l1 * a1;
+        m_run = m;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] * a1;
+      }
+    }
+    if (kpar != 0) return;
+  }
   if (q_live && qrow < p.Sq) {
     const float inv = 1.0f / l_run;
     uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
@@ -350,12 +385,13 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
   }
 }
 
-template <typename T, int DP, int SKV_MAX>
+template <typename T, int DP, int SKV_MAX, int KS2 = 1>
 int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
   constexpr int lds = SKV_MAX * (DP * 2 + 16) + DP * (SKV_MAX * 2 + 8);
+
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<T, DP, SKV_MAX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<T, DP, SKV_MAX, KS2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
@@ -363,8 +399,12 @@ int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
   int nw = nw_req > 0 ? nw_req : q_tiles;
   if (nw > 12) nw = 12;
   if (nw > q_tiles) nw = q_tiles;
-  dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw);
-  hipLaunchKernelGGL((attn_resident_kernel<T, DP, SKV_MAX>), grid, block, lds, stream, p);
+  if (KS2 > 1 && nw * (DP / 32 * 16 + 2) * 256 > lds) {   // merge buffer (one parked (m, l, O) state per query tile) reuses the K/V windows
+    stllm_set_error("stllm_attention: key-split merge buffer does not fit (nw=%d)", nw);
+    return STLLM_ERR_UNSUPPORTED;
+  }
+  dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw * KS2);
+  hipLaunchKernelGGL((attn_resident_kernel<T, DP, SKV_MAX, KS2>), grid, block, lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_attention(resident)");
   return STLLM_OK;
 }
@@ -434,11 +474,11 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
   //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
   if (p.D == 88) {
     if (p.Sq <= 32) return launch_mfma<T, 96, 1>(p, stream);                       // BT-Adapter temporal attention
-    if (p.Skv <= 288 && !p.causal) return launch_resident<T, 96, 288>(p, stream);  // ViT: K/V of a head resident in LDS
+    if (p.Skv <= 288 && !p.causal) return launch_resident<T, 96, 288>(p, stream);  // ViT: K/V of a head resident in LDS (a key split here re-stages K/V per query chunk: 26 -> 37 us)
     return launch_mfma<T, 96, 3>(p, stream);
   }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
-  if (p.D == 128) return launch_resident<T, 128, 128>(p, stream, 3);  // 128-key windows (2 workgroups/CU), 96 queries per workgroup
+  if (p.D == 128) return launch_resident<T, 128, 128, 4>(p, stream, 3);   // + four waves per query tile (every 4th key tile each)  // 128-key windows (2 workgroups/CU), 96 queries per workgroup
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
   return STLLM_ERR_UNSUPPORTED;
 }
