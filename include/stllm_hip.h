@@ -105,6 +105,11 @@ int64_t stllm_gemm_workspace_bytes(void);
  * (the split-K exchanges poll with a bound instead of hanging the GPU when not all workgroups are resident, e.g. on a
  * GPU shared with another process), non-zero otherwise (sticky; stllm_last_error() explains). */
 int stllm_gemm_workspace_status(const void* workspace, void* stream);
+/* Host-only introspection of the phased kernel's schedule for an M x N x K problem (no GPU needed; used by the CPU tests):
+ * plan5 = { data-parallel rounds q, remainder tiles r, K slices per remainder tile s, slice groups per XCD cap, estimated us }
+ * for tile_rows = 192 | 256; heavy = 0 plain 16-bit output, 1 fp32 output / residual, 2 GELU.  T = q * 256 + r tiles of
+ * tile_rows x 256; the s workgroups of a remainder tile sit on one XCD (s <= 32, 8 * cap >= r, cap = 32 / s). */
+int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)

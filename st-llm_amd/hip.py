@@ -21,7 +21,7 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_set_option"]
+           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_set_option"]
 
 
 def torch_dtype(d):
@@ -79,6 +79,7 @@ def lib():
         L.stllm_gemm_workspace_bytes.restype = c_int64
         L.stllm_set_option.argtypes = [c_char_p, c_int]
         L.stllm_gemm_workspace_status.argtypes = [c_void_p, c_void_p]
+        L.stllm_gemm_plan.argtypes = [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]
         _lib = L
     return _lib
 
@@ -118,6 +119,13 @@ def gemm_workspace(device):
         ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{key}")
         _workspaces[key] = ws
     return ws
+
+
+def gemm_plan(M, N, K, heavy=0, tile_rows=192):
+    """(q, r, s, cap, est_us) of the phased kernel's schedule (host-only, see stllm_hip.h)."""
+    out = (c_int * 5)()
+    _check(lib().stllm_gemm_plan(M, N, K, heavy, tile_rows, out), "stllm_gemm_plan")
+    return tuple(out)
 
 
 def gemm_workspace_ok(device=None):

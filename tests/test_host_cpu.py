@@ -34,6 +34,34 @@ def test_abi_exports_match_header():
     assert L.stllm_abi_version() == 1
 
 
+def test_phased_gemm_schedule_invariants():
+    """Host logic of the phased GEMM (st-llm_amd/csrc/gemm_p8.inc, make_plan): every tile is covered exactly once, the K
+    slices of a remainder tile fit one XCD's 32 workgroups, and the hot-path shapes get the schedules DESIGN.md describes."""
+    from stllm_amd import hip
+    shapes_ = [(4112, 4224, 1408), (4112, 1408, 1408), (4112, 6144, 1408), (4112, 1408, 6144), (576, 12288, 4096),
+               (576, 4096, 4096), (576, 22016, 4096), (576, 4096, 11008), (576, 32000, 4096), (4096, 4096, 4096),
+               (1, 128, 64), (300, 384, 192), (100000, 256, 64), (257, 128 * 77, 64 * 9)]
+    for rows in (192, 256):
+        for M, N, K in shapes_:
+            for heavy in (0, 1, 2):
+                q, r, s, cap, est = hip.gemm_plan(M, N, K, heavy, rows)
+                tiles = -(-M // rows) * -(-N // 256)
+                assert q * 256 + r == tiles and 0 <= r < 256, (M, N, K, rows, q, r)
+                assert 1 <= s <= 32 and cap == 32 // s and est > 0
+                if r:
+                    assert 8 * cap >= r, "every remainder tile needs its own group of s workgroups on one XCD"
+                    assert s <= K // 64, "no empty K slice"
+                else:
+                    assert s == 1
+    # the Llama prefill shapes of config 2 (M = 576 = 3 x 192: no padding with the 192-row tile)
+    assert hip.gemm_plan(576, 4096, 11008, 1, 192)[:4] == (0, 48, 5, 6)       # down_proj: 48 tiles x 5 K-slices = 240 workgroups
+    assert hip.gemm_plan(576, 22016, 4096, 0, 192)[:3] == (1, 2, 16)          # gate/up: one full round + 2 tiles split 16 ways (cost model: 0.3 us per peer)
+    assert hip.gemm_plan(576, 12288, 4096, 0, 192)[:3] == (0, 144, 1)         # qkv: 144 tiles admit no XCD-local split
+    assert hip.gemm_plan(4096, 4096, 4096, 0, 256)[:3] == (1, 0, 1)           # 256 tiles: pure data-parallel
+    with pytest.raises(RuntimeError):
+        hip.gemm_plan(576, 4096, 100, 0, 192)                                  # K must be a multiple of 64
+
+
 def test_hip_path_has_no_cpu_fallback():
     from stllm_amd import hip
     a = torch.zeros(8, 64, dtype=torch.bfloat16)
