@@ -119,6 +119,20 @@ int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);
 
 /*
+ * Frame preprocessing in front of the path — replaces the CPU transform chain of Chat.__init__ / upload_video
+ * (stllm/conversation/conversation.py:190-198, 276-279; stllm/test/video_transforms.py:54-60, 94-124, 367-407):
+ *   GroupScale(224, BICUBIC) -> GroupCenterCrop(224) -> Stack -> ToTorchFormatTensor -> GroupNormalize(CLIP mean / std)
+ * frames: uint8 RGB [n, H, W, 3] (frame n at frames + n * frame_stride_bytes);  out: f32 [n, 3, 224, 224].
+ * Bit-identical to torchvision 0.15.1 + Pillow on the CPU: short side -> 224 with Pillow's antialiased bicubic (22-bit
+ * fixed-point coefficients, horizontal then vertical pass, uint8 in between), centre crop with round-half-even offsets,
+ * x / 255, (x - mean) / std in fp32.  Down-scaling up to ~31x.  `workspace`: >= stllm_preprocess_workspace_bytes(n, H, W)
+ * bytes of device memory, 16-byte aligned, no initialisation needed (coefficient tables + the uint8 image between the passes).
+ */
+int64_t stllm_preprocess_workspace_bytes(int n_frames, int H, int W);   /* -1: unsupported geometry */
+int stllm_preprocess_frames(const uint8_t* frames, int64_t frame_stride_bytes, int n_frames, int H, int W, float* out,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * LayerNorm over the last dim of x f32[M,D] (ldx), fp32 statistics (two-pass), affine.
  * Writes out_t T[M,D] (ldo_t) and/or out_f32 [M,D] (ldo_f); either may be NULL.
  * Replaces nn.LayerNorm at eva_vit.py:157,163 (eps 1e-6), blip2.py:103-109 (ln_vision, eps 1e-5),

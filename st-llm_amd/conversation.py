@@ -1,11 +1,13 @@
 """Tensor path of the reference's Chat wrapper (stllm/conversation/conversation.py:181-340): what
 ``demo.py`` drives — ``upload_video`` -> ``encode_img`` -> pooling -> prompt-embedding concat ->
-``generate(inputs_embeds=...)``.  Video decoding, PIL transforms, prompt templates and stopping criteria are
+``generate(inputs_embeds=...)``.  The frame transform (resize / crop / normalise, conversation.py:190-198) runs on the
+GPU (processors.VideoTransform); video decoding, prompt templates and stopping criteria are
 host-side text/media utilities and out of scope."""
 import torch
 
 from . import hip, runtime
 from .models.st_llm import get_residual_index
+from .processors import VideoTransform, is_raw_frames
 
 
 class Chat:
@@ -14,9 +16,14 @@ class Chat:
         self.LLM = model
         # conversation.py:185-190 — the visual front-end hangs off model.model (or model.model.model under peft)
         self.model = model.model.stllm_model if hasattr(model.model, "stllm_model") else model.model.model.stllm_model
+        self.transform = VideoTransform(device)   # conversation.py:190-198
 
     def upload_video(self, video, conv, img_list, num_frame=64, text=None):
-        """conversation.py:274-299 with `video` already a frames tensor ([T*3,224,224] or [T,3,224,224], CLIP-normalised)."""
+        """conversation.py:274-299.  `video`: decoded raw frames (uint8 RGB [T,H,W,3] / list of PIL images — what the
+        reference's load_video returns; transformed on the GPU by processors.VideoTransform == self.transform) or an already
+        transformed frames tensor ([T*3,224,224] or [T,3,224,224], CLIP-normalised)."""
+        if is_raw_frames(video):
+            video = self.transform(video)
         frames = video.to(self.device)
         if frames.dim() == 3:
             bt, w, h = frames.shape

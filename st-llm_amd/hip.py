@@ -21,7 +21,8 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_set_option"]
+           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_set_option",
+           "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames"]
 
 
 def torch_dtype(d):
@@ -79,6 +80,9 @@ def lib():
         L.stllm_gemm_workspace_bytes.restype = c_int64
         L.stllm_set_option.argtypes = [c_char_p, c_int]
         L.stllm_gemm_workspace_status.argtypes = [c_void_p, c_void_p]
+        L.stllm_preprocess_workspace_bytes.restype = c_int64
+        L.stllm_preprocess_workspace_bytes.argtypes = [c_int, c_int, c_int]
+        L.stllm_preprocess_frames.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]
         L.stllm_gemm_plan.argtypes = [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]
         _lib = L
     return _lib
@@ -119,6 +123,23 @@ def gemm_workspace(device):
         ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{key}")
         _workspaces[key] = ws
     return ws
+
+
+def preprocess_frames(frames_u8, out=None):
+    """uint8 RGB frames [T, H, W, 3] on the GPU -> CLIP-normalised f32 [T, 3, 224, 224] (see stllm_hip.h)."""
+    _req(frames_u8, torch.uint8, "frames")
+    if frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise RuntimeError(f"frames must be uint8 [T, H, W, 3], got {tuple(frames_u8.shape)}")
+    f = frames_u8.contiguous()
+    T_, H, W, _ = f.shape
+    need = int(lib().stllm_preprocess_workspace_bytes(T_, H, W))
+    if need < 0:
+        raise RuntimeError(f"preprocess_frames: unsupported frame size {H}x{W}")
+    ws = torch.empty(need, dtype=torch.uint8, device=f.device)
+    if out is None:
+        out = torch.empty((T_, 3, 224, 224), dtype=torch.float32, device=f.device)
+    _check(lib().stllm_preprocess_frames(_p(f), f.stride(0), T_, H, W, _p(out), _p(ws), need, _stream()), "stllm_preprocess_frames")
+    return out
 
 
 def gemm_plan(M, N, K, heavy=0, tile_rows=192):
