@@ -449,10 +449,18 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
 
     @classmethod
     def get_state_dict(cls, path, prefix="pytorch_model"):
+        """st_llm.py:149-158: merge the `pytorch_model-XXXXX-of-YYYYY.bin` shards of a HF directory.  Beyond the reference:
+        `model-XXXXX-of-YYYYY.safetensors` shards (what current HF exports write) are merged the same way."""
         pattern = re.compile(f"{prefix}-(\\d+)-of-(\\d+).bin")
         sd = {}
-        for fn in [f for f in os.listdir(path) if pattern.match(f)]:
+        for fn in sorted(f for f in os.listdir(path) if pattern.match(f)):
             sd.update(torch.load(os.path.join(path, fn), map_location="cpu"))
+        st_pattern = re.compile(r"model-(\d+)-of-(\d+)\.safetensors")
+        st_files = sorted(f for f in os.listdir(path) if st_pattern.match(f))
+        if st_files and not sd:
+            from safetensors.torch import load_file
+            for fn in st_files:
+                sd.update(load_file(os.path.join(path, fn), device="cpu"))
         return sd
 
     @classmethod
