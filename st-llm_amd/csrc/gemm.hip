@@ -815,6 +815,7 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
 // stream-K eligibility + tile: returns 0 (off) | 1 = 128x128 | 2 = 128x256 | 3 = 256x256
 static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): -1 auto, 0 off, 1/2/3 force a tile
 static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
+static int g_gemv_mode = -2;  // stllm_set_option("gemm_gemv")
 static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 phased kernel (3 / 4: force 192 / 256 rows)
 static int sk_choice(const GemmParams& p, int eb) {
   if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
@@ -887,6 +888,14 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
+    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): 0 = keep M <= 4 on the tile kernels
+    if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
+    if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4;   // tests / experiments
+    if (p.M <= 4 && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
+      const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
+      if (rc != STLLM_ERR_UNSUPPORTED) return rc;
+    }
     int miw = 4;
     const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
                     : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;
@@ -982,6 +991,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;
 }

@@ -58,4 +58,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 int stllm_sk_next_epoch();   // gemm.hip: launch epoch shared by all kernels that use the workspace flag array
 int stllm_gemm_p8_launch_bf16(int epilogue, int miw, const sg::GemmParams& p, hipStream_t stream);
 int stllm_gemm_p8_launch_f16(int epilogue, int miw, const sg::GemmParams& p, hipStream_t stream);
+// skinny GEMM of the decode regime (gemv.hip): M <= 4, 16-bit dtypes, every epilogue except PATCH
+int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream);
 float stllm_gemm_p8_estimate_us(int M, int N, int K, int heavy_epilogue, int* miw);   // cost model of the schedule; picks MIW (4: 256 rows, 3: 192 rows)

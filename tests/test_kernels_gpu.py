@@ -353,6 +353,57 @@ def test_gemm_phased_auto_dispatch(hip):
     assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()   # no split-K exchange of this process ever timed out
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (256, 11008), (1536, 704)])
+def test_gemv_decode_regime(hip, dtype, M, N, K):
+    """skinny kernel of the decode regime (M <= 4, gemv.hip): every epilogue against fp64, K tails (K % 512 != 0), strided output rows"""
+    from stllm_amd import pack
+    a, a64 = rnd("a", (M, K), dtype, 0.5)
+    w, w64 = rnd("w", (N, K), dtype, 0.05)
+    b = T("b", (N,), 0.5)
+    ref = a64 @ w64.t() + b.double()
+    out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+    assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel<"), hip.lib().stllm_last_kernel().decode()
+    check(out, ref, ACC_TOL[dtype], "gemv store f32")
+    check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "gemv gelu T")
+    x = T("x", (M, N), 2.0)
+    xd = x.cuda()
+    hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+    check(xd, x.double() + ref, ACC_TOL[dtype], "gemv resid")
+    # output rows with a stride (the decode step writes one row per sequence into the KV cache buffer)
+    buf = torch.zeros((M, 3, N), device="cuda", dtype=hip.torch_dtype(dtype))
+    hip.gemm(a, w, dtype=dtype, out=buf[:, 1])
+    check(buf[:, 1], a64 @ w64.t(), OUT_TOL[dtype], "gemv strided rows")
+    assert float(buf[:, 0].abs().max()) == 0.0 and float(buf[:, 2].abs().max()) == 0.0
+    if N % 128 == 0 and K % 64 == 0 and N >= 1024:
+        I = N // 2
+        wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+        wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+        o = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
+        assert "gemv_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(o, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "gemv swiglu")
+        H, D = N // 3 // 128, 128
+        if H >= 1 and H * 3 * 128 == N:
+            wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+            wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+            wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+            S = 7
+            cos, sin = pack.rope_tables(S)
+            pos = 5   # decode: every row sits at position `pos` (rope_seq = 1 with a one-row table slice)
+            qkv = hip.gemm(a, pack.llama_qkv(wq, wk, wv, dtype, n_heads=H), dtype=dtype, epilogue=hip.EPI_ROPE,
+                           rope=(cos[pos:pos + 1].cuda(), sin[pos:pos + 1].cuda()), rope_seq=1, rope_cols=2 * H * D).double().cpu().view(M, 3, H, D)
+            c, s_ = O.rope_tables(S, D)
+            q = (a64 @ wq64.t()).view(M, H, D)
+            k = (a64 @ wk64.t()).view(M, H, D)
+            q = q * c[pos].double() + O._rotate_half(q) * s_[pos].double()
+            k = k * c[pos].double() + O._rotate_half(k) * s_[pos].double()
+            perm = pack.rope_head_perm(1)
+            check(qkv[:, 0], q[..., perm], OUT_TOL[dtype], "gemv q rope")
+            check(qkv[:, 1], k[..., perm], OUT_TOL[dtype], "gemv k rope")
+            check(qkv[:, 2], (a64 @ wv64.t()).view(M, H, D), OUT_TOL[dtype], "gemv v")
+
+
 def test_gemm_rejects_bad_shapes(hip):
     a = torch.zeros((8, 100), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
