@@ -120,6 +120,18 @@ int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);
 
 /*
+ * Decode attention: ONE query row per (batch, head) against Skv cached keys (the one-token step of generate(), SURVEY §8f
+ * rank 1; HF LlamaAttention with past_key_values, spec modeling_llama_mem.py:172-248).  HBM-bound: the keys are split over
+ * several workgroups per head and the partial softmax states are merged by a second launch.  head_dim 128, bf16 / fp16.
+ * q: element (b, h, d) at q[b*q_bs + h*128 + d];  k, v: (b, s, h, d) at k[b*k_bs + s*k_rs + h*128 + d];  out like q.
+ * workspace: >= stllm_attention_decode_workspace_bytes(B, H, Skv) bytes, 16-byte aligned, no initialisation needed.
+ */
+int64_t stllm_attention_decode_workspace_bytes(int B, int H, int Skv);
+int stllm_attention_decode(int dtype, const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs,
+                           const void* v, int64_t v_bs, int64_t v_rs, void* out, int64_t o_bs, int B, int H, int Skv,
+                           int D, float scale, void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Frame preprocessing in front of the path — replaces the CPU transform chain of Chat.__init__ / upload_video
  * (stllm/conversation/conversation.py:190-198, 276-279; stllm/test/video_transforms.py:54-60, 94-124, 367-407):
  *   GroupScale(224, BICUBIC) -> GroupCenterCrop(224) -> Stack -> ToTorchFormatTensor -> GroupNormalize(CLIP mean / std)

@@ -485,6 +485,97 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// =====================================================================================================
+// Decode attention (Sq = 1 against a KV cache): HBM-bound streaming of K and V.
+// The tile kernels above give one query tile per head = 32 workgroups walking the cache serially (38 us per layer
+// at Skv = 580).  Here the keys are split across `nsplit` workgroups per (batch, head):
+//   partial kernel: 4 waves per workgroup, wave w takes keys k0 + w, k0 + w + 4, ...; lane l owns dims 2l, 2l+1
+//     (one 4-byte load per lane = one coalesced 256-byte row per wave), score = butterfly-reduced dot, online softmax
+//     in the exp2 domain, O accumulated in 2 registers per lane; the 4 waves merge through LDS and write (m, l, O[128]);
+//   merge kernel: one workgroup per (batch, head) combines the nsplit partials and writes the output row.
+// =====================================================================================================
+constexpr int kDecD = 128;
+constexpr int kDecRec = kDecD + 2;   // floats per partial record: m, l, O[128]
+
+template <typename T> __device__ __forceinline__ void widen2(uint32_t u, float& a, float& b);
+template <> __device__ __forceinline__ void widen2<bf16_t>(uint32_t u, float& a, float& b) {
+  a = __builtin_bit_cast(float, u << 16);
+  b = __builtin_bit_cast(float, u & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void widen2<f16_t>(uint32_t u, float& a, float& b) {
+  a = (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu));
+  b = (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const AttnParams p, float* __restrict__ ws, int nsplit, int keys_per_split) {
+  __shared__ float part[4][kDecRec];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sp = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int k0 = sp * keys_per_split, k1 = min(p.Skv, k0 + keys_per_split);
+  float q0, q1;
+  widen2<T>(*reinterpret_cast<const uint32_t*>(p.q + ((int64_t)b * p.q_bs + (int64_t)h * kDecD + 2 * lane) * 2), q0, q1);
+  q0 *= p.scale_log2;
+  q1 *= p.scale_log2;
+  const char* kb = p.k + ((int64_t)b * p.k_bs + (int64_t)h * kDecD + 2 * lane) * 2;
+  const char* vb = p.v + ((int64_t)b * p.v_bs + (int64_t)h * kDecD + 2 * lane) * 2;
+  float m = kNeg, l = 0.0f, o0 = 0.0f, o1 = 0.0f;
+  for (int key = k0 + wave; key < k1; key += 4) {
+    float ka, kc, va, vc;
+    widen2<T>(*reinterpret_cast<const uint32_t*>(kb + (int64_t)key * p.k_rs * 2), ka, kc);
+    widen2<T>(*reinterpret_cast<const uint32_t*>(vb + (int64_t)key * p.v_rs * 2), va, vc);
+    const float s = wave_sum(fmaf(q0, ka, q1 * kc));   // log2-domain score, identical in every lane
+    const float mn = fmaxf(m, s);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn), pr = __builtin_amdgcn_exp2f(s - mn);
+    l = fmaf(l, alpha, pr);
+    o0 = fmaf(o0, alpha, pr * va);
+    o1 = fmaf(o1, alpha, pr * vc);
+    m = mn;
+  }
+  if (lane == 0) { part[wave][0] = m; part[wave][1] = l; }
+  part[wave][2 + 2 * lane] = o0;
+  part[wave][3 + 2 * lane] = o1;
+  __syncthreads();
+  if (wave == 0) {
+    float mm = fmaxf(fmaxf(part[0][0], part[1][0]), fmaxf(part[2][0], part[3][0]));
+    float ll = 0.0f, a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __builtin_amdgcn_exp2f(part[w][0] - mm);
+      ll = fmaf(part[w][1], f, ll);
+      a0 = fmaf(part[w][2 + 2 * lane], f, a0);
+      a1 = fmaf(part[w][3 + 2 * lane], f, a1);
+    }
+    float* rec = ws + (((int64_t)b * p.H + h) * nsplit + sp) * kDecRec;
+    if (lane == 0) { rec[0] = mm; rec[1] = ll; }
+    rec[2 + 2 * lane] = a0;
+    rec[3 + 2 * lane] = a1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_merge_kernel(const AttnParams p, const float* __restrict__ ws, int nsplit) {
+  const int lane = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+  const float* rec = ws + ((int64_t)b * p.H + h) * nsplit * kDecRec;
+  float mm = kNeg;
+  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, rec[s * kDecRec]);
+  float ll = 0.0f, a0 = 0.0f, a1 = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float f = __builtin_amdgcn_exp2f(rec[s * kDecRec] - mm);
+    ll = fmaf(rec[s * kDecRec + 1], f, ll);
+    a0 = fmaf(rec[s * kDecRec + 2 + 2 * lane], f, a0);
+    a1 = fmaf(rec[s * kDecRec + 3 + 2 * lane], f, a1);
+  }
+  const float inv = 1.0f / ll;
+  uint32_t* op = reinterpret_cast<uint32_t*>(p.o + ((int64_t)b * p.o_bs + (int64_t)h * kDecD + 2 * lane) * 2);
+  *op = Elem<T>::pack2(a0 * inv, a1 * inv);
+}
+
+static int decode_splits(int Skv) {
+  int n = (Skv + 47) / 48;   // ~48 keys (12 per wave) per workgroup
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
 extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs,
                                int64_t k_rs, const void* v, int64_t v_bs, int64_t v_rs, void* out, int64_t o_bs,
                                int64_t o_rs, int B, int H, int Sq, int Skv, int D, float scale, int causal,
@@ -518,4 +609,43 @@ extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q
   }
   stllm_set_error("stllm_attention: bad dtype %d", dtype);
   return STLLM_ERR_BAD_DTYPE;
+}
+
+extern "C" int64_t stllm_attention_decode_workspace_bytes(int B, int H, int Skv) {
+  if (B <= 0 || H <= 0 || Skv <= 0) return -1;
+  return (int64_t)B * H * decode_splits(Skv) * kDecRec * 4;
+}
+
+extern "C" int stllm_attention_decode(int dtype, const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_rs,
+                                      const void* v, int64_t v_bs, int64_t v_rs, void* out, int64_t o_bs, int B, int H, int Skv,
+                                      int D, float scale, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  STLLM_CHECK_ARG(q && k && v && out && workspace, "stllm_attention_decode: null pointer");
+  STLLM_CHECK_ARG(B > 0 && H > 0 && Skv > 0, "stllm_attention_decode: empty problem");
+  STLLM_CHECK_ARG(D == kDecD, "stllm_attention_decode: head_dim %d != 128", D);
+  STLLM_CHECK_ARG(dtype == STLLM_BF16 || dtype == STLLM_F16, "stllm_attention_decode: 16-bit dtypes only");
+  STLLM_CHECK_ARG(((uintptr_t)q & 3) == 0 && ((uintptr_t)k & 3) == 0 && ((uintptr_t)v & 3) == 0 && ((uintptr_t)out & 3) == 0 &&
+                      q_bs % 2 == 0 && k_bs % 2 == 0 && k_rs % 2 == 0 && v_bs % 2 == 0 && v_rs % 2 == 0 && o_bs % 2 == 0,
+                  "stllm_attention_decode: pointers / strides must be 4-byte aligned");
+  const int nsplit = decode_splits(Skv);
+  STLLM_CHECK_ARG(workspace_bytes >= stllm_attention_decode_workspace_bytes(B, H, Skv) && aligned16(workspace),
+                  "stllm_attention_decode: workspace too small or misaligned");
+  AttnParams p{};
+  p.q = (const char*)q; p.q_bs = q_bs;
+  p.k = (const char*)k; p.k_bs = k_bs; p.k_rs = k_rs;
+  p.v = (const char*)v; p.v_bs = v_bs; p.v_rs = v_rs;
+  p.o = (char*)out; p.o_bs = o_bs;
+  p.B = B; p.H = H; p.Sq = 1; p.Skv = Skv; p.D = D;
+  p.scale = scale; p.scale_log2 = scale * 1.44269504088896340736f;
+  float* ws = reinterpret_cast<float*>(workspace);
+  const int kps = (Skv + nsplit - 1) / nsplit;
+  if (dtype == STLLM_BF16) {
+    hipLaunchKernelGGL(attn_decode_partial_kernel<bf16_t>, dim3(nsplit, H, B), dim3(256), 0, stream, p, ws, nsplit, kps);
+    hipLaunchKernelGGL(attn_decode_merge_kernel<bf16_t>, dim3(H, B), dim3(64), 0, stream, p, ws, nsplit);
+  } else {
+    hipLaunchKernelGGL(attn_decode_partial_kernel<f16_t>, dim3(nsplit, H, B), dim3(256), 0, stream, p, ws, nsplit, kps);
+    hipLaunchKernelGGL(attn_decode_merge_kernel<f16_t>, dim3(H, B), dim3(64), 0, stream, p, ws, nsplit);
+  }
+  STLLM_CHECK_LAUNCH("stllm_attention_decode");
+  return STLLM_OK;
 }

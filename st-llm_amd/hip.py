@@ -22,7 +22,8 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
            "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_set_option",
-           "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames"]
+           "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
+           "stllm_attention_decode"]
 
 
 def torch_dtype(d):
@@ -83,6 +84,10 @@ def lib():
         L.stllm_preprocess_workspace_bytes.restype = c_int64
         L.stllm_preprocess_workspace_bytes.argtypes = [c_int, c_int, c_int]
         L.stllm_preprocess_frames.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]
+        L.stllm_attention_decode_workspace_bytes.restype = c_int64
+        L.stllm_attention_decode_workspace_bytes.argtypes = [c_int, c_int, c_int]
+        L.stllm_attention_decode.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                             c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]
         L.stllm_gemm_plan.argtypes = [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]
         _lib = L
     return _lib
@@ -281,6 +286,9 @@ def rmsnorm(x, gamma, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want
     return out_t, out_f32
 
 
+_decode_attn = True   # tests flip this to compare the split-KV decode kernel with the tile kernels
+
+
 def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, out=None,
               q_strides=None, k_strides=None, v_strides=None):
     """q/k/v: 2-D views [B*S, >=H*D] of the compute dtype (may be column slices of a fused QKV buffer).
@@ -292,6 +300,12 @@ def attention(q, k, v, *, B, H, Sq, Skv, D, scale, causal=False, kv_len=None, ou
     qs, ks, vs = st(q, Sq, q_strides), st(k, Skv, k_strides), st(v, Skv, v_strides)
     if out is None:
         out = torch.empty((B * Sq, H * D), device=q.device, dtype=td)
+    if Sq == 1 and D == 128 and kv_len is None and td in (torch.bfloat16, torch.float16) and _decode_attn:
+        need = int(lib().stllm_attention_decode_workspace_bytes(B, H, Skv))   # one-token decode: keys split over workgroups
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _check(lib().stllm_attention_decode(dtype_code(td), _p(q), qs[0], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1], _p(out),
+                                            out.stride(0), B, H, Skv, D, scale, _p(ws), need, _stream()), "stllm_attention_decode")
+        return out
     if kv_len is not None:
         _req(kv_len, torch.int32, "kv_len")
     _check(lib().stllm_attention(dtype_code(td), _p(q), qs[0], qs[1], _p(k), ks[0], ks[1], _p(v), vs[0], vs[1],

@@ -404,6 +404,33 @@ def test_gemv_decode_regime(hip, dtype, M, N, K):
             check(qkv[:, 2], (a64 @ wv64.t()).view(M, H, D), OUT_TOL[dtype], "gemv v")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,H,Skv", [(1, 32, 580), (2, 4, 1), (3, 2, 47), (1, 8, 2048), (2, 3, 97)])
+def test_attention_decode_split_kv(hip, dtype, B, H, Skv):
+    """one-token decode against a KV cache laid out like LlamaModel's (fused [B, max_len, 3*H*128] buffer): the split-KV
+    kernel vs fp64 softmax(q K^T / sqrt(d)) V and vs the tile kernel it replaces"""
+    D, max_len = 128, Skv + 5
+    td = hip.torch_dtype(dtype)
+    cache, c64 = rnd("kvcache", (B * max_len, 3 * H * D), dtype)
+    full = cache.view(B * max_len, 3 * H * D)
+    row = cache.view(B, max_len, 3 * H * D)[:, Skv - 1]                       # the newest token's fused QKV row: [B, 3HD] strided view
+    ML3 = max_len * 3 * H * D
+    kw = dict(B=B, H=H, Sq=1, Skv=Skv, D=D, scale=D ** -0.5, causal=False, q_strides=(ML3, 3 * H * D), k_strides=(ML3, 3 * H * D),
+              v_strides=(ML3, 3 * H * D))
+    got = hip.attention(row[:, :H * D], full[:, H * D:2 * H * D], full[:, 2 * H * D:], **kw)
+    c = c64.view(B, max_len, 3, H, D)
+    q = c[:, Skv - 1, 0]                                                        # [B, H, D]
+    k, v = c[:, :Skv, 1].transpose(1, 2), c[:, :Skv, 2].transpose(1, 2)        # [B, H, Skv, D]
+    ref = (torch.softmax((q.unsqueeze(2) @ k.transpose(-1, -2)) * D ** -0.5, dim=-1) @ v).reshape(B, H * D)
+    check(got, ref, 2 * OUT_TOL[dtype], "decode attention vs fp64")
+    hip._decode_attn = False
+    try:
+        tile = hip.attention(row[:, :H * D], full[:, H * D:2 * H * D], full[:, 2 * H * D:], **kw)
+    finally:
+        hip._decode_attn = True
+    check(got, tile.double().cpu(), 2 * OUT_TOL[dtype], "decode attention vs tile kernel")
+
+
 def test_gemm_rejects_bad_shapes(hip):
     a = torch.zeros((8, 100), device="cuda", dtype=torch.bfloat16)
     w = torch.zeros((128, 100), device="cuda", dtype=torch.bfloat16)
