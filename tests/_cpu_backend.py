@@ -156,12 +156,22 @@ def set_profiler(p):
     pass
 
 
+def preprocess_frames(frames_u8, out=None):
+    """stllm_preprocess_frames via the oracle (tests only): uint8 [T,H,W,3] -> f32 [T,3,224,224]"""
+    import preprocess_oracle as P
+    r = torch.from_numpy(P.video_transform(frames_u8.cpu().numpy())).view(-1, 3, 224, 224)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 @contextlib.contextmanager
 def installed():
     """Monkey-patch stllm_amd.hip's compute entry points with the functions above (tests only)."""
     from stllm_amd import hip
     names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
-             "cross_entropy_rows", "cast_rows"]
+             "cross_entropy_rows", "cast_rows", "preprocess_frames"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

@@ -182,3 +182,23 @@ def test_frame_parallel_model_matches_single_process(cfg_name):
             n = min(a.shape[0], b.shape[0])
             assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 1e-5, f"rank {rank} clip {c}"
     assert sorted(seen) == [0, 1, 2]
+
+
+def test_chat_upload_raw_frames_on_host_graph():
+    """Chat.upload_video on decoded uint8 frames (conversation.py:276-279: transform, then `.view(bt // 3, 3, w, h)`) feeds the
+    encoder exactly what the pre-transformed tensor does."""
+    import numpy as np
+    import preprocess_oracle as P
+    from stllm_amd import runtime
+    from stllm_amd.conversation import Chat
+    cfg = CFGS["mean_pooling"]
+    model = build(cfg)
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, (2, 150, 200, 3), dtype=np.uint8)
+    pre = torch.from_numpy(P.video_transform(raw))                       # [6, 224, 224]
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        chat = Chat(model, device="cpu")
+        a, b = [], []
+        chat.upload_video(raw, None, a)
+        chat.upload_video(pre, None, b)
+    assert torch.equal(a[0], b[0])
