@@ -55,10 +55,20 @@ class Chat:
         question = (conv.system if system else "") + "###Human: " + question + " ###Assistant: "
         return self.get_context_emb_ids(img_list, self.model.llama_tokenizer.encode_ids(question, add_special_tokens=False))
 
-    def answer(self, img_list, question_ids, max_new_tokens=300, max_length=2000, **kw):
-        """conversation.py:213-253: keep the last `max_length` embeddings, then generate."""
+    def answer(self, img_list, question_ids, max_new_tokens=300, num_beams=1, min_length=1, top_p=0.9,
+               repetition_penalty=1.0, length_penalty=1, temperature=1.0, max_length=2000, do_sample=False,
+               stopping_criteria=None, **kw):
+        """conversation.py:213-253: keep the last `max_length - max_new_tokens` embeddings, generate with the reference's
+        knobs (demo.py: num_beams=5, do_sample=False), drop a leading <unk> (0) / <s> (1) token."""
         embs, att = self.get_context_emb_ids(img_list, question_ids)
         begin = max(0, embs.shape[1] - (max_length - max_new_tokens))
         embs = embs[:, begin:]
-        out = self.LLM.generate(inputs_embeds=embs, max_new_tokens=max_new_tokens, **kw)
-        return self.model.llama_tokenizer.decode(out[0].tolist()), out[0].cpu().numpy()
+        out = self.LLM.generate(inputs_embeds=embs, max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria,
+                                num_beams=num_beams, do_sample=do_sample, min_length=min_length, top_p=top_p,
+                                repetition_penalty=repetition_penalty, length_penalty=length_penalty, temperature=temperature, **kw)
+        tok = out[0]
+        if tok.numel() and int(tok[0]) == 0:   # conversation.py:246-249
+            tok = tok[1:]
+        if tok.numel() and int(tok[0]) == 1:
+            tok = tok[1:]
+        return self.model.llama_tokenizer.decode(tok.tolist()), tok.cpu().numpy()

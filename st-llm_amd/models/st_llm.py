@@ -415,37 +415,18 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
 
     @torch.no_grad()
     def generate(self, inputs_embeds=None, max_new_tokens=16, num_beams=1, do_sample=False, stopping_criteria=None,
-                 attention_mask=None, use_cache=True, **unused):
-        """Greedy decoding: HIP prefill of `inputs_embeds` into a KV cache, then one decode step per new token
-        (conversation.py:231-243 hands off to HF generate; beam search / sampling / repetition penalty stay out of scope).
-        Returns the generated ids [B, n_new] (the prompt has no ids)."""
-        if num_beams != 1 or do_sample:
-            raise NotImplementedError("beam search / sampling stay with HF generate in the reference; greedy only here")
-        emb = inputs_embeds.float()
-        B, S, _ = emb.shape
-        lm = self.model
-        out_ids = []
-        if use_cache:
-            cache = lm.new_cache(B, S + max_new_tokens, emb.device)
-            hidden, h16 = lm.prefill(emb, None, cache=cache)
-            logits = self.logits_from(h16.view(B, S, -1)[:, -1].contiguous(), B, 1)[:, 0]
-        for i in range(max_new_tokens):
-            if not use_cache:
-                logits = self.forward(samples=None, inputs_embeds=emb).logits[:, -1]
-            nxt = logits.argmax(dim=-1)
-            out_ids.append(nxt)
-            ids_so_far = torch.stack(out_ids, dim=1)
-            if stopping_criteria is not None and any(sc(ids_so_far, None) for sc in stopping_criteria):
-                break
-            if i + 1 == max_new_tokens:
-                break
-            tok = lm.embed_tokens(nxt.view(B, 1).cpu())
-            if use_cache:
-                _, h16 = lm.decode_step(tok, cache)
-                logits = self.logits_from(h16, B, 1)[:, 0]
-            else:
-                emb = torch.cat([emb, tok], dim=1)
-        return torch.stack(out_ids, dim=1)
+                 attention_mask=None, use_cache=True, min_length=0, top_p=1.0, repetition_penalty=1.0, length_penalty=1.0,
+                 temperature=1.0, eos_token_id=2, pad_token_id=0, generator=None, **unused):
+        """`llama_model.generate(inputs_embeds=..., ...)` as Chat.answer calls it (conversation.py:231-243; demo.py runs
+        num_beams=5, do_sample=False): HIP prefill of `inputs_embeds` into a KV cache, then one decode step per token with
+        HF's greedy / sampling / beam-search bookkeeping restated in stllm_amd/generation.py.  eos / pad default to the
+        Vicuna generation config (2 / 0).  Returns the generated ids [B, n] (the prompt has no ids)."""
+        from .. import generation
+        return generation.generate(self, inputs_embeds, max_new_tokens=max_new_tokens, num_beams=num_beams, do_sample=do_sample,
+                                   min_length=min_length, top_p=top_p, temperature=temperature,
+                                   repetition_penalty=repetition_penalty, length_penalty=length_penalty,
+                                   stopping_criteria=stopping_criteria, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                   use_cache=use_cache, generator=generator)
 
     @classmethod
     def get_state_dict(cls, path, prefix="pytorch_model"):

@@ -202,3 +202,26 @@ def test_chat_upload_raw_frames_on_host_graph():
         chat.upload_video(raw, None, a)
         chat.upload_video(pre, None, b)
     assert torch.equal(a[0], b[0])
+
+
+def test_chat_answer_beam_search_on_host_graph():
+    """Chat.answer with the demo's decoding mode (demo.py:58-66: beam search, no sampling) runs end to end on the host graph and
+    equals a direct generate() on the same context embeddings."""
+    import numpy as np
+    from stllm_amd import runtime
+    from stllm_amd.conversation import Chat
+    cfg = CFGS["mean_pooling"]
+    model = build(cfg)
+    frames = T("input.frames2", (2, 3, 224, 224))
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        chat = Chat(model, device="cpu")
+        img_list = []
+        chat.upload_video(frames.view(6, 224, 224), None, img_list)
+        text, ids = chat.answer(img_list, [21, 22, 23], max_new_tokens=4, num_beams=3, do_sample=False)
+        embs, _ = chat.get_context_emb_ids(img_list, [21, 22, 23])
+        direct = model.generate(inputs_embeds=embs, max_new_tokens=4, num_beams=3, min_length=1)
+    d = direct[0]
+    while d.numel() and int(d[0]) in (0, 1) and d.numel() > ids.size:
+        d = d[1:]
+    assert np.array_equal(ids, d.numpy()) and len(ids) <= 4
+    assert text == model.model.stllm_model.llama_tokenizer.decode(ids.tolist())
