@@ -68,7 +68,7 @@ def cpu_baseline(T, S, budget_s=25.0):
     cores = min(os.cpu_count() or 1, 64)   # more threads than this only adds fork/join overhead at these sizes
     torch.set_num_threads(cores)
     rnd = lambda shp: {k: torch.randn(v) * 0.02 for k, v in shp.items()}
-    NF, VB, QL, LL = 8, 4, 6, 4      # sample: 8 frames x 4/39 ViT blocks, 8 frames x 6/12 Q-Former layers, 4/32 Llama layers
+    NF, VB, QL, LL = 16, 8, 12, 8    # sample: 16 frames x 8/39 ViT blocks, 16 frames x 12/12 Q-Former layers, 8/32 Llama layers (~10-20 s of CPU work)
     with torch.no_grad():
         sd = rnd(shapes.vit_shapes(VB, "v."))
         fr = torch.randn(NF, 3, 224, 224)
