@@ -48,3 +48,17 @@ def test_resize_vs_pillow_live():
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BICUBIC))
         assert np.array_equal(P.pil_resize_bicubic_u8(img, ow, oh), ref), (h, w, oh, ow)
+
+
+def test_workspace_geometry_host_side():
+    """stllm_preprocess_workspace_bytes is pure host arithmetic (no GPU): coefficient tables + the uint8 image between the passes."""
+    from stllm_amd import hip
+    L = hip.lib()
+    # 360x640 -> 224x398: ksize_h = 2*ceil(2*640/398)+1 = 9, ksize_v = 2*ceil(2*360/224)+1 = 9
+    tabs = 2 * (2 * 224 + 224 * 9) * 4
+    assert L.stllm_preprocess_workspace_bytes(16, 360, 640) == -(-tabs // 256) * 256 + 16 * 360 * 224 * 3
+    # no resampling at all: identity tables (one tap per output)
+    assert L.stllm_preprocess_workspace_bytes(1, 224, 224) == -(-(2 * (2 * 224 + 224) * 4) // 256) * 256 + 224 * 224 * 3
+    assert L.stllm_preprocess_workspace_bytes(0, 360, 640) == -1
+    assert L.stllm_preprocess_workspace_bytes(1, 224 * 40, 224 * 40) == -1          # > 31x down-scaling: more taps than the kernel holds
+    assert L.stllm_preprocess_workspace_bytes(1, 100, 150) > 0                       # up-scaling is fine
