@@ -363,6 +363,32 @@ def fx_chat():
          last_logits=out.logits[0, -1].numpy()[::7])
 
 
+GEN_CASES = [(4.0, 3), (4.0, 4), (8.0, 4), (8.0, 5)]   # (lm_head scale, prompt seed): beam search != greedy in two of them
+GEN_MODES = [dict(num_beams=1), dict(num_beams=5), dict(num_beams=3, repetition_penalty=1.3, length_penalty=2.0)]
+
+
+def fx_generate():
+    """§8f rank 1: `llama_model.generate(inputs_embeds=...)` exactly as Chat.answer calls it (conversation.py:231-243; demo.py runs
+    num_beams=5, do_sample=False) on the reference's own STLLMForCausalLM (2-layer Llama, synthetic weights, lm_head scaled so that
+    the next-token distribution has structure).  Stores only the generated ids; prompts regenerate from (name, seed)."""
+    cfg = _Cfg(dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="", video_input="mean", use_mask=False,
+                    mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2", vit_precision="fp32"))
+    model = fill_stllm(_build_ref_stllm(cfg, 1, 2, 2))
+    w0 = model.lm_head.weight.detach().clone()
+    out = {}
+    for scale, seed in GEN_CASES:
+        with torch.no_grad():
+            model.lm_head.weight.copy_(w0 * scale)
+        emb = T(f"gen.emb{seed}", (1, 9, 4096), 0.05)
+        for mi, kw in enumerate(GEN_MODES):
+            k = dict(dict(max_new_tokens=6, do_sample=False, min_length=1, top_p=0.9, repetition_penalty=1.0, length_penalty=1,
+                          temperature=1.0), **kw)
+            ids = model.generate(inputs_embeds=emb, **k)[0]
+            out[f"s{scale:g}_p{seed}_m{mi}"] = ids.numpy().astype(np.int64)
+            print(scale, seed, kw, ids.tolist())
+    save("generate", **out)
+
+
 def fx_c1_full():
     """Config 1, FULL SIZE: B1 T4, EVA-CLIP-g 39 blocks + 12-layer Q-Former + Vicuna-7B 32 layers,
     InstructBLIP-style (residual R=4 of T=4 == all frames, text Q-Former).  Stores a logits summary."""
@@ -389,7 +415,7 @@ def fx_c1_full():
 
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
            stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip,
-           btadapter=fx_btadapter, chat=fx_chat)
+           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate)
 SLOW = dict(c1_full=fx_c1_full)
 
 if __name__ == "__main__":

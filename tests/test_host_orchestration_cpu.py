@@ -225,3 +225,26 @@ def test_chat_answer_beam_search_on_host_graph():
         d = d[1:]
     assert np.array_equal(ids, d.numpy()) and len(ids) <= 4
     assert text == model.model.stllm_model.llama_tokenizer.decode(ids.tolist())
+
+
+def test_generate_matches_reference_fixture():
+    """tests/golden/generate.npz holds the ids the REFERENCE's STLLMForCausalLM.generate produced (greedy, num_beams=5 as in demo.py,
+    num_beams=3 with repetition / length penalties) with the arguments of conversation.py:231-243; the product's generate() on the
+    same synthetic weights and prompts must produce the same ids (host graph on the test-only CPU backend, fp32)."""
+    from stllm_amd import runtime
+    from _util import golden
+    g = golden("generate")
+    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=2)
+    w0 = model.lm_head.weight.detach().clone()
+    modes = [dict(num_beams=1), dict(num_beams=5), dict(num_beams=3, repetition_penalty=1.3, length_penalty=2.0)]
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        for scale, seed in [(4.0, 3), (4.0, 4), (8.0, 4), (8.0, 5)]:
+            with torch.no_grad():
+                model.lm_head.weight.copy_(w0 * scale)
+            model._lm_packed = {}          # the packed lm_head copy is cached per dtype
+            emb = T(f"gen.emb{seed}", (1, 9, 4096), 0.05)
+            for mi, kw in enumerate(modes):
+                k = dict(dict(max_new_tokens=6, do_sample=False, min_length=1, top_p=0.9, repetition_penalty=1.0, length_penalty=1,
+                              temperature=1.0), **kw)
+                ids = model.generate(inputs_embeds=emb, **k)[0].tolist()
+                assert ids == g[f"s{scale:g}_p{seed}_m{mi}"].tolist(), (scale, seed, kw, ids)
