@@ -10,6 +10,19 @@ from .models.st_llm import get_residual_index
 from .processors import VideoTransform, is_raw_frames
 
 
+class StoppingCriteriaSub:
+    """conversation.py:105-116: stop as soon as the FIRST row ends in one of the stop sequences ('###' has two encodings)."""
+
+    def __init__(self, stops=(), encounters=1):
+        self.stops = list(stops)
+
+    def __call__(self, input_ids, scores):
+        for stop in self.stops:
+            if torch.all((stop.to(input_ids.device) == input_ids[0][-len(stop):])).item():
+                return True
+        return False
+
+
 class Chat:
     def __init__(self, model, device="cuda:0"):
         self.device = device
@@ -17,6 +30,8 @@ class Chat:
         # conversation.py:185-190 — the visual front-end hangs off model.model (or model.model.model under peft)
         self.model = model.model.stllm_model if hasattr(model.model, "stllm_model") else model.model.model.stllm_model
         self.transform = VideoTransform(device)   # conversation.py:190-198
+        # conversation.py:199-201: '###' ends an answer
+        self.stopping_criteria = [StoppingCriteriaSub(stops=[torch.tensor([835]), torch.tensor([2277, 29937])])]
 
     def upload_video(self, video, conv, img_list, num_frame=64, text=None):
         """conversation.py:274-299.  `video`: decoded raw frames (uint8 RGB [T,H,W,3] / list of PIL images — what the
@@ -63,6 +78,8 @@ class Chat:
         embs, att = self.get_context_emb_ids(img_list, question_ids)
         begin = max(0, embs.shape[1] - (max_length - max_new_tokens))
         embs = embs[:, begin:]
+        if stopping_criteria is None:
+            stopping_criteria = self.stopping_criteria
         out = self.LLM.generate(inputs_embeds=embs, max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria,
                                 num_beams=num_beams, do_sample=do_sample, min_length=min_length, top_p=top_p,
                                 repetition_penalty=repetition_penalty, length_penalty=length_penalty, temperature=temperature, **kw)

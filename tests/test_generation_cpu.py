@@ -103,3 +103,12 @@ def test_sampling_is_seeded_and_top_p_restricts():
     greedy = _run_mine(mine, emb, max_new_tokens=5)
     tiny_p = _run_mine(mine, emb, max_new_tokens=5, do_sample=True, top_p=1e-6, generator=g())   # nucleus of one token == greedy
     assert torch.equal(tiny_p, greedy)
+
+
+def test_stopping_criteria_sub_semantics():
+    """conversation.py:105-116, including its behaviour on rows shorter than a stop sequence (broadcast compare)"""
+    from stllm_amd.conversation import StoppingCriteriaSub
+    sc = StoppingCriteriaSub(stops=[torch.tensor([835]), torch.tensor([2277, 29937])])
+    assert sc(torch.tensor([[5, 835]]), None) and sc(torch.tensor([[1, 2277, 29937], [0, 0, 0]]), None)
+    assert not sc(torch.tensor([[835, 5]]), None) and not sc(torch.tensor([[2277]]), None)
+    assert not sc(torch.tensor([[7, 7], [5, 835]]), None)          # only the first row is looked at
