@@ -174,7 +174,7 @@ def test_chat_upload_video_and_prefill(mode, tol):
     if mode == "fp32":
         # greedy generate(): first token must be the argmax of the golden first-step logits slice owner
         ids = model.generate(inputs_embeds=embs, max_new_tokens=2)
-        assert ids.shape == (1, 2)
+        assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 2      # (an EOS as first token ends the row, HF semantics)
         assert int(ids[0, 0]) == int(out.logits[0, -1].argmax())
 
 
