@@ -548,7 +548,8 @@ def stllm_forward(samples: dict, sd: SD, cfg: dict):
     hid = llama_forward(ie, am, sd, "model.", nh)
     out = {"inputs_embeds": ie, "attention_mask": am, "targets": targets, "loss_mvm": None}
     if un is not None:
-        uh = llama_forward(ue, ua, sd, "model.", nh)
+        with torch.no_grad():                      # st_llm.py:77-83: the un-masked pass is the (detached) target
+            uh = llama_forward(ue, ua, sd, "model.", nh)
         img_start = 0 if cfg.get("qformer_text_input", False) else 8
         out["loss_mvm"] = mvm_loss(hid, uh, mask, img_start, un.shape[2], emb.shape[2], sd, p)
     logits = lm_logits(hid, sd)

@@ -389,6 +389,54 @@ def fx_generate():
     save("generate", **out)
 
 
+def fx_backward():
+    """gradients of the reference's training loss (st_llm.py:125-138, CE + loss_mvm) w.r.t. every parameter
+    the reference leaves trainable with freeze_vit / freeze_qformer = True and freeze_LLM = False (config/*_stllm_qa.yaml):
+    llama_proj, down/up_proj, mvm_decoder, and the whole LLM (embed_tokens, layers, norm, lm_head).  loss.backward() through the
+    reference's own STLLMForCausalLM.forward(samples) on CPU fp32; per parameter we keep (L2 norm, abs-max, mean) and a strided
+    slice.  The injected mask is the one the reference drew (numpy seed 1234)."""
+    cases = {
+        "mvm": (dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="", video_input="all",
+                     use_mask=True, mvm_decode=True, qformer_text_input=False, max_txt_len=32, end_sym=" 2",
+                     vit_precision="fp32"), 4),
+        "residual": (dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="",
+                          video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
+                          qformer_text_input=True, max_txt_len=32, end_sym=" 2", vit_precision="fp32"), 8),
+    }
+    arrs = {}
+    for tag, (cfg, Tn) in cases.items():
+        cfg = _Cfg(cfg)
+        model = fill_stllm(_build_ref_stllm(cfg, 1, 2, 2))
+        samples, meta = _samples(2, Tn, cfg.get("qformer_text_input", False))
+        np.random.seed(1234)
+        with torch.enable_grad():
+            out = model(samples=samples)
+            out.loss.backward()
+        sm = model.model.stllm_model
+        names = []
+        for n, prm in model.named_parameters():
+            if prm.grad is None:
+                continue
+            names.append(n)
+            g = prm.grad
+            arrs[f"{tag}.stats.{n}"] = stats(g)
+            arrs[f"{tag}.slice.{n}"] = sub(g, 97, 101) if g.dim() == 2 else sub(g, 29)
+        frozen = [n for n, prm in model.named_parameters() if prm.grad is None]
+        assert all(n.startswith(("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
+                                 "model.stllm_model.query_tokens")) for n in frozen), frozen[:5]
+        arrs[f"{tag}.names"] = np.array(names)
+        arrs[f"{tag}.loss"] = np.array([out.loss.item()])
+        text = cfg.get("qformer_text_input", False)       # effective id streams, as in fx_stllm
+        arrs[f"{tag}.before"] = _ragged(meta["before"])
+        arrs[f"{tag}.after"] = _ragged([([1] if text else []) + meta["after"][i] + (meta["qtext"][i] if text else []) for i in range(2)])
+        arrs[f"{tag}.answer"] = _ragged([a + [2] for a in meta["answer"]])
+        arrs[f"{tag}.qtext"] = _ragged(meta["qtext"])
+        if cfg.get("use_mask", False):
+            arrs[f"{tag}.mask"] = sm.mask.squeeze(1).numpy()
+        print(tag, "loss", out.loss.item(), "trainable tensors", len(names), "frozen", len(frozen))
+    save("backward", **arrs)
+
+
 def fx_c1_full():
     """Config 1, FULL SIZE: B1 T4, EVA-CLIP-g 39 blocks + 12-layer Q-Former + Vicuna-7B 32 layers,
     InstructBLIP-style (residual R=4 of T=4 == all frames, text Q-Former).  Stores a logits summary."""
@@ -415,7 +463,7 @@ def fx_c1_full():
 
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
            stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip,
-           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate)
+           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward)
 SLOW = dict(c1_full=fx_c1_full)
 
 if __name__ == "__main__":

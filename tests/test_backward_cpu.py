@@ -1,0 +1,78 @@
+"""CPU (-m "not gpu"): SURVEY.md §8f rank 3 — gradients of the training loss.
+
+1. The oracle (autograd over oracle/stllm_oracle.py) against the gradients the REFERENCE produced here
+   (tests/golden/backward.npz, written by make_fixtures.py fx_backward: loss.backward() through the reference's own
+   STLLMForCausalLM.forward(samples), CPU fp32) — pins the gradient oracle.
+2. The product's explicit backward graph (stllm_amd/training.py) on the test-only CPU backend against the oracle.
+Tolerances: fp32 everywhere, 2e-4 relative to each tensor's abs-max (sums over up to ~350 tokens x 4096 features)."""
+import numpy as np
+import pytest
+import torch
+
+import shapes
+import stllm_oracle as O
+from _util import T, golden, sd_from, stats, sub, unragged
+
+CASES = {
+    "mvm": (dict(vit_model="eva_clip_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False), 4),
+    "residual": (dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
+                      qformer_text_input=True), 8),
+}
+FROZEN = ("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
+          "model.stllm_model.query_tokens")
+
+
+def case_inputs(tag):
+    g = golden("backward")
+    cfg, Tn = CASES[tag]
+    text = cfg["qformer_text_input"]
+    sdshape = {**shapes.stllm_model_shapes(1, 2, text, cfg["video_input"], cfg.get("mvm_decode", False), qf_vocab=32000),
+               **shapes.llama_shapes(2)}
+    sd = sd_from(sdshape)
+    samples = {"image": T("input.video", (2, Tn, 3, 224, 224)), "before_ids": unragged(g[f"{tag}.before"]),
+               "after_ids": unragged(g[f"{tag}.after"]), "answer_ids": unragged(g[f"{tag}.answer"])}
+    if text:
+        qt = [[1] + r for r in unragged(g[f"{tag}.qtext"])]
+        L = max(len(r) for r in qt)
+        ids = torch.zeros(2, L, dtype=torch.long)
+        m = torch.zeros(2, L, dtype=torch.long)
+        for i, r in enumerate(qt):
+            ids[i, :len(r)] = torch.tensor(r)
+            m[i, :len(r)] = 1
+        samples["qformer_ids"], samples["qformer_mask"] = ids, m
+    if cfg.get("use_mask"):
+        samples["mask"] = torch.from_numpy(g[f"{tag}.mask"])
+    return g, cfg, sd, samples
+
+
+def oracle_grads(cfg, sd, samples):
+    train = [n for n in sd if not n.startswith(FROZEN)]
+    for n in train:
+        sd[n].requires_grad_(True)
+    with torch.enable_grad():
+        out = O.stllm_forward(samples, sd, dict(cfg, pad_id=0, bos_id=1))
+        out["loss"].backward()
+    grads = {n: sd[n].grad for n in train if sd[n].grad is not None}
+    for n in train:
+        sd[n].requires_grad_(False)
+    return out["loss"].item(), grads
+
+
+def check_against_fixture(g, tag, loss, grads, rtol):
+    names = [str(n) for n in g[f"{tag}.names"]]
+    assert sorted(names) == sorted(grads), set(names) ^ set(grads)
+    assert abs(loss - g[f"{tag}.loss"][0]) < 2e-4 * max(1.0, abs(g[f"{tag}.loss"][0]))
+    for n in names:
+        gr = grads[n]
+        want = g[f"{tag}.slice.{n}"]
+        got = sub(gr, 97, 101) if gr.dim() == 2 else sub(gr, 29)
+        st = g[f"{tag}.stats.{n}"]
+        assert np.abs(got - want).max() <= rtol * st[1], (n, np.abs(got - want).max(), st[1])
+        assert abs(stats(gr)[0] - st[0]) <= rtol * st[0], (n, stats(gr)[0], st[0])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_oracle_gradients_match_reference(tag):
+    g, cfg, sd, samples = case_inputs(tag)
+    loss, grads = oracle_grads(cfg, sd, samples)
+    check_against_fixture(g, tag, loss, grads, 2e-4)
