@@ -374,3 +374,210 @@ def cast_rows(x, dtype, out=None):
 
 def set_option(key, value):
     _check(lib().stllm_set_option(key.encode(), int(value)), "stllm_set_option")
+
+
+# ----------------------------------------------------------------------------------------------
+# Training entry points (include/stllm_hip.h "backward / optimizer").  Same rules: device pointers,
+# current stream, no fallback.
+TRAIN_EXPORTS = ["stllm_transpose", "stllm_norm_bwd_workspace_bytes", "stllm_rmsnorm_bwd", "stllm_layernorm_bwd", "stllm_swiglu",
+                 "stllm_swiglu_bwd", "stllm_rope_bwd", "stllm_attention_bwd", "stllm_cross_entropy_bwd", "stllm_scatter_add_rows",
+                 "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
+EXPORTS += TRAIN_EXPORTS
+_train_bound = False
+
+
+def _tlib():
+    global _train_bound
+    L = lib()
+    if not _train_bound:
+        i64, i, f, p = c_int64, c_int, c_float, c_void_p
+        L.stllm_transpose.argtypes = [i, p, i64, p, i64, i, i, i, p]
+        L.stllm_norm_bwd_workspace_bytes.restype = c_int64
+        L.stllm_norm_bwd_workspace_bytes.argtypes = [i, i]
+        L.stllm_rmsnorm_bwd.argtypes = [i, p, i64, p, f, p, i64, p, i64, i, p, p, i64, i, i, p]
+        L.stllm_layernorm_bwd.argtypes = [i, p, i64, p, f, p, i64, p, i64, i, p, p, p, i64, i, i, p]
+        L.stllm_swiglu.argtypes = [i, p, i64, p, i64, i, i, p]
+        L.stllm_swiglu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
+        L.stllm_rope_bwd.argtypes = [i, p, i64, p, p, i, i, i, i, p]
+        L.stllm_attention_bwd.argtypes = [i] + [p, i64, i64] * 7 + [i, i, i, i, f, i, p, p]
+        L.stllm_cross_entropy_bwd.argtypes = [i, p, i64, p, f, p, i64, i, i, i, p]
+        L.stllm_scatter_add_rows.argtypes = [p, i64, p, p, i64, p, i64, i, i, f, p]
+        L.stllm_cosine_rows_bwd.argtypes = [p, i64, p, p, i64, p, f, p, i64, i, i, p]
+        L.stllm_colsum.argtypes = [i, p, i64, p, i, i, p, i64, p]
+        L.stllm_relu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
+        L.stllm_bcast_add_t.argtypes = [p, p, i, i, i64, f, p]
+        L.stllm_adamw.argtypes = [p, p, p, p, p, i, i64, f, f, f, f, f, i, f, p]
+        L.stllm_sumsq.argtypes = [p, i64, p, p]
+        for n in TRAIN_EXPORTS:
+            if n != "stllm_norm_bwd_workspace_bytes":
+                getattr(L, n).restype = c_int
+        _train_bound = True
+    return L
+
+
+def _colws(rows, cols, device):
+    need = int(_tlib().stllm_norm_bwd_workspace_bytes(rows, cols))
+    return torch.empty(need, dtype=torch.uint8, device=device), need
+
+
+def transpose(x, *, pad=64, out=None):
+    """x [R, C] (bf16 / f16 / f32, row-strided) -> out [C, Rp], Rp = R rounded up to `pad`; out[c, r] = x[r, c], 0 for r >= R.
+    (Operand re-layout for the dgrad / wgrad GEMMs: stllm_gemm contracts over the contiguous dim of both operands.)"""
+    _req(x, None, "x")
+    R, C = x.shape
+    Rp = (R + pad - 1) // pad * pad
+    if out is None:
+        out = torch.empty((C, Rp), device=x.device, dtype=x.dtype)
+    _check(_tlib().stllm_transpose(dtype_code(x.dtype), _p(x), x.stride(0), _p(out), out.stride(0), R, C, Rp, _stream()), "stllm_transpose")
+    return out
+
+
+def rmsnorm_bwd(x, gamma, eps, dy, dx, *, accumulate=True):
+    """y = gamma * x * rsqrt(mean(x^2) + eps).  x f32 [M,D]; dy [M,D] (compute dtype or f32); dx f32 [M,D] (+= if accumulate).
+    Returns dgamma f32 [D] (deterministic two-stage column reduction)."""
+    _req(x, torch.float32, "x"); _req(dx, torch.float32, "dx"); _req(dy, None, "dy")
+    M, D = x.shape
+    dgamma = torch.empty((D,), device=x.device, dtype=torch.float32)
+    ws, need = _colws(M, D, x.device)
+    _check(_tlib().stllm_rmsnorm_bwd(dtype_code(dy.dtype), _p(x), x.stride(0), _p(gamma), eps, _p(dy), dy.stride(0), _p(dx), dx.stride(0),
+                                     int(accumulate), _p(dgamma), _p(ws), need, M, D, _stream()), "stllm_rmsnorm_bwd")
+    return dgamma
+
+
+def layernorm_bwd(x, gamma, eps, dy, dx=None, *, accumulate=False):
+    """LayerNorm backward (fp32 statistics).  x f32 [M,D], dy [M,D] -> (dx f32 [M,D], dgamma [D], dbeta [D])."""
+    _req(x, torch.float32, "x"); _req(dy, None, "dy")
+    M, D = x.shape
+    if dx is None:
+        dx = torch.empty((M, D), device=x.device, dtype=torch.float32)
+        accumulate = False
+    dgamma = torch.empty((D,), device=x.device, dtype=torch.float32)
+    dbeta = torch.empty((D,), device=x.device, dtype=torch.float32)
+    ws, need = _colws(M, D, x.device)
+    _check(_tlib().stllm_layernorm_bwd(dtype_code(dy.dtype), _p(x), x.stride(0), _p(gamma), eps, _p(dy), dy.stride(0), _p(dx), dx.stride(0),
+                                       int(accumulate), _p(dgamma), _p(dbeta), _p(ws), need, M, D, _stream()), "stllm_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def swiglu(gu, out=None):
+    """gu [M, 2I] in the packed [32 gate | 32 up] groups of pack.llama_gate_up -> silu(gate) * up [M, I] (compute dtype)."""
+    _req(gu, None, "gu")
+    M, N2 = gu.shape
+    if out is None:
+        out = torch.empty((M, N2 // 2), device=gu.device, dtype=gu.dtype)
+    _check(_tlib().stllm_swiglu(dtype_code(gu.dtype), _p(gu), gu.stride(0), _p(out), out.stride(0), M, N2 // 2, _stream()), "stllm_swiglu")
+    return out
+
+
+def swiglu_bwd(gu, dg, out=None):
+    """d(silu(gate) * up) -> d[gate | up] in the packed layout of `gu`.  gu [M,2I], dg [M,I] -> [M,2I] (compute dtype)."""
+    _req(gu, None, "gu"); _req(dg, gu.dtype, "dg")
+    M, N2 = gu.shape
+    if out is None:
+        out = torch.empty((M, N2), device=gu.device, dtype=gu.dtype)
+    _check(_tlib().stllm_swiglu_bwd(dtype_code(gu.dtype), _p(gu), gu.stride(0), _p(dg), dg.stride(0), _p(out), out.stride(0), M, N2 // 2,
+                                    _stream()), "stllm_swiglu_bwd")
+    return out
+
+
+def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
+    """Transpose of the ROPE epilogue's rotation, in place on the first `rope_cols` columns of dqkv [M, N] (packed head layout)."""
+    _req(dqkv, None, "dqkv"); _req(cos, torch.float32, "cos"); _req(sin, torch.float32, "sin")
+    M, N = dqkv.shape
+    _check(_tlib().stllm_rope_bwd(dtype_code(dqkv.dtype), _p(dqkv), dqkv.stride(0), _p(cos), _p(sin), M, N, rope_seq, rope_cols, _stream()),
+           "stllm_rope_bwd")
+    return dqkv
+
+
+def attention_bwd(q, k, v, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
+                  d_strides=None):
+    """Gradients of softmax(scale * q k^T + masks) v.  q/k/v/dq/dk/dv: 2-D views of the compute dtype as in `attention`
+    (strides = (batch_stride, row_stride) in elements, shared by q, k, v; d_strides by dq, dk, dv); do [B*S, H*D]."""
+    td = q.dtype
+
+    def st(t, given):
+        return given if given is not None else (S * t.stride(0), t.stride(0))
+    s_, ds_, os_ = st(q, strides), st(dq, d_strides), st(do, do_strides)
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len")
+    a = [dtype_code(td)]
+    for t, ss in ((q, s_), (k, s_), (v, s_), (do, os_), (dq, ds_), (dk, ds_), (dv, ds_)):
+        a += [_p(t), ss[0], ss[1]]
+    _check(_tlib().stllm_attention_bwd(*a, B, H, S, D, scale, int(causal), _p(kv_len), _stream()), "stllm_attention_bwd")
+    return dq, dk, dv
+
+
+def cross_entropy_bwd(logits, labels, scale, *, dtype, vocab=None):
+    """d(sum of per-row CE) * scale w.r.t. logits: (softmax - onehot) * scale for rows with label >= 0, 0 otherwise.
+    logits f32 [n, Vp] (columns >= vocab are padding), labels int32 [n] -> [n, Vp] in `dtype`, padding columns 0."""
+    _req(logits, torch.float32, "logits"); _req(labels, torch.int32, "labels")
+    n, Vp = logits.shape
+    V = Vp if vocab is None else vocab
+    out = torch.empty((n, Vp), device=logits.device, dtype=torch_dtype(dtype))
+    _check(_tlib().stllm_cross_entropy_bwd(dtype_code(out.dtype), _p(logits), logits.stride(0), _p(labels), scale, _p(out), out.stride(0),
+                                           n, V, Vp, _stream()), "stllm_cross_entropy_bwd")
+    return out
+
+
+def scatter_add_rows(src, idx, dst_a, dst_b=None, scale=1.0):
+    """Transpose of gather_rows: dst_a[idx[i]] += scale * src[i] (idx >= 0) or dst_b[-idx[i]-1] += scale * src[i] (fp32 atomics)."""
+    _req(src, torch.float32, "src"); _req(idx, torch.int32, "idx"); _req(dst_a, torch.float32, "dst_a")
+    n, D = idx.numel(), src.shape[-1]
+    _check(_tlib().stllm_scatter_add_rows(_p(src), src.stride(0), _p(idx), _p(dst_a), dst_a.stride(0), _p(dst_b),
+                                          dst_b.stride(0) if dst_b is not None else 0, n, D, scale, _stream()), "stllm_scatter_add_rows")
+
+
+def cosine_rows_bwd(a, b, idx_a=None, idx_b=None, n_rows=None, scale=1.0):
+    """Gradient of sum_i scale * (2 - 2 cos(a_i, b_i)) w.r.t. the (gathered) a rows -> f32 [n, D]; b is a constant target."""
+    n = n_rows if n_rows is not None else (idx_a.numel() if idx_a is not None else a.shape[0])
+    out = torch.empty((n, a.shape[-1]), device=a.device, dtype=torch.float32)
+    _check(_tlib().stllm_cosine_rows_bwd(_p(a), a.stride(0), _p(idx_a), _p(b), b.stride(0), _p(idx_b), scale, _p(out), out.stride(0), n,
+                                         a.shape[-1], _stream()), "stllm_cosine_rows_bwd")
+    return out
+
+
+def colsum(x):
+    """sum over rows of x [M, N] (any dtype) -> f32 [N] (bias gradients)."""
+    _req(x, None, "x")
+    M, N = x.shape
+    out = torch.empty((N,), device=x.device, dtype=torch.float32)
+    ws, need = _colws(M, N, x.device)
+    _check(_tlib().stllm_colsum(dtype_code(x.dtype), _p(x), x.stride(0), _p(out), M, N, _p(ws), need, _stream()), "stllm_colsum")
+    return out
+
+
+def relu_bwd(dy, y):
+    """dy * (y > 0), same dtype as dy."""
+    _req(dy, None, "dy"); _req(y, dy.dtype, "y")
+    out = torch.empty_like(dy)
+    M, N = dy.shape
+    _check(_tlib().stllm_relu_bwd(dtype_code(dy.dtype), _p(dy), dy.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), M, N, _stream()),
+           "stllm_relu_bwd")
+    return out
+
+
+def bcast_add_t(dst, src, scale):
+    """Transpose of mean_t: dst f32 [B,T,...] += scale * src f32 [B,...] for every t."""
+    _req(dst, torch.float32, "dst"); _req(src, torch.float32, "src")
+    assert dst.is_contiguous() and src.is_contiguous()
+    B, T = dst.shape[0], dst.shape[1]
+    _check(_tlib().stllm_bcast_add_t(_p(dst), _p(src), B, T, dst[0, 0].numel(), scale, _stream()), "stllm_bcast_add_t")
+
+
+def adamw(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p16=None):
+    """torch.optim.AdamW's update on flat fp32 state, in place; optionally also writes the compute-dtype copy p16."""
+    for t, w in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, w)
+        assert t.is_contiguous()
+    _check(_tlib().stllm_adamw(_p(p), _p(g), _p(m), _p(v), _p(p16), dtype_code(p16.dtype) if p16 is not None else 0, p.numel(), lr, beta1,
+                               beta2, eps, weight_decay, step, grad_scale, _stream()), "stllm_adamw")
+
+
+def sumsq(x, out=None):
+    """out[0] += sum(x^2) (fp32; gradient-norm clipping)."""
+    _req(x, torch.float32, "x")
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.zeros((1,), device=x.device, dtype=torch.float32)
+    _check(_tlib().stllm_sumsq(_p(x), x.numel(), _p(out), _stream()), "stllm_sumsq")
+    return out

@@ -58,6 +58,8 @@ def get_residual_index(sample_segments, total_segments):
 
 
 class STLLMModel(Blip2Base):
+    _tape = None   # stllm_amd.training sets a dict here: forward() then records what its backward needs (no effect otherwise)
+
     def __init__(self, vit_model="eva_clip_g", q_former_model="", img_size=224, pre_encoding=False, use_mask=False,
                  mvm_decode=False, video_input=None, residual_size=4, qformer_text_input=False, drop_path_rate=0,
                  use_grad_checkpoint=False, vit_precision="fp16", freeze_vit=True, has_qformer=True,
@@ -146,6 +148,8 @@ class STLLMModel(Blip2Base):
         if self.qformer_text_input:
             ids, tmask = self._qformer_ids(text, n, T)
         _, hq16, _ = self.Qformer.bert.encode(self.query_tokens[0], enc16, n, ids, tmask)
+        if self._tape is not None:
+            self._tape["hq16"] = hq16
         w, b = self.llama_proj.packed(dt)
         inputs_llama = hip.gemm(hq16, w, dtype=dt, bias=b, out_f32=True).view(n, -1, 4096)
         if not infer:
@@ -170,6 +174,8 @@ class STLLMModel(Blip2Base):
     def pool_video(self, img_embeds):
         """st_llm.py:463-478 — [B,T,32,D] -> [B,1,L,D] ('all' | 'mean' | 'residual' global-local module)."""
         B, T, Lq, D = img_embeds.shape
+        if self._tape is not None:
+            self._tape["pool_shape"] = (B, T, Lq, D)
         if self.video_input == "all":
             return img_embeds.reshape(B, 1, T * Lq, D).contiguous()
         if self.video_input == "mean":
@@ -181,7 +187,8 @@ class STLLMModel(Blip2Base):
             g = hip.mean_t(img_embeds.contiguous()).view(B * Lq, D)  # the reference expands to R copies first: same values
             wd, bd = self.down_proj.packed(dt)
             wu, bu = self.up_proj.packed(dt)
-            h = hip.gemm(hip.cast_rows(g, dt), wd, dtype=dt, bias=bd, act=hip.ACT_RELU)
+            g16 = hip.cast_rows(g, dt)
+            h = hip.gemm(g16, wd, dtype=dt, bias=bd, act=hip.ACT_RELU)
             gg = hip.gemm(h, wu, dtype=dt, bias=bu, out_f32=True)
             b_i = torch.arange(B).view(B, 1, 1)
             r_i = torch.as_tensor(ridx).view(1, R, 1)
@@ -189,6 +196,8 @@ class STLLMModel(Blip2Base):
             idx = ((b_i * T + r_i) * Lq + l_i).reshape(-1).to(torch.int32).to(img_embeds.device)
             idx_add = (b_i * Lq + l_i).expand(B, R, Lq).reshape(-1).to(torch.int32).to(img_embeds.device)
             out = hip.gather_rows(img_embeds.reshape(-1, D), idx, add=gg, idx_add=idx_add)
+            if self._tape is not None:
+                self._tape.update(pool_g16=g16, pool_h=h, pool_idx=idx, pool_idx_add=idx_add)
             return out.view(B, 1, R * Lq, D)
         return img_embeds
 
@@ -204,6 +213,8 @@ class STLLMModel(Blip2Base):
         B, S = len(rows), len(rows[0])
         idx = torch.tensor(rows, dtype=torch.int32).reshape(-1).to(vis_flat.device)
         out = hip.gather_rows(vis_flat, idx, src_b=self.embed_tokens.weight)
+        if self._tape is not None:
+            self._tape.setdefault("gather_idx", []).append(idx)
         return out.view(B, S, vis_flat.shape[-1])
 
     def _assemble(self, L_total, kept, instruction, answers_ids, B):
@@ -295,6 +306,8 @@ class STLLMModel(Blip2Base):
                                   max_length=self.max_txt_len, add_special_tokens=False)
         answers = [tr.input_ids[b][: int(tr.attention_mask[b].sum())].tolist() for b in range(B)]
         vis_flat = img_embeds.reshape(B * L, D)
+        if self._tape is not None:
+            self._tape.update(vis_rows=B * L, pooled=not use_image)
         rows, attention_mask, targets = self._assemble(L, kept, instruction, answers, B)
         inputs_embeds = self._gather_tokens(vis_flat, rows)
         un_e = un_a = None

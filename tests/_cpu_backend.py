@@ -166,12 +166,168 @@ def preprocess_frames(frames_u8, out=None):
     return r
 
 
+# ---- training entry points (contracts: include/stllm_hip.h "backward / optimizer") -----------------------------------
+def transpose(x, *, pad=64, out=None):
+    R, C = x.shape
+    Rp = (R + pad - 1) // pad * pad
+    o = torch.zeros((C, Rp), dtype=x.dtype)
+    o[:, :R] = x.t()
+    return o
+
+
+def rmsnorm_bwd(x, gamma, eps, dy, dx, *, accumulate=True):
+    xf, g = x.float(), gamma.float() * dy.float()
+    r = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    xh = xf * r
+    d = r * (g - xh * (g * xh).mean(-1, keepdim=True))
+    if accumulate:
+        dx += d
+    else:
+        dx.copy_(d)
+    return (dy.float() * xh).sum(0)
+
+
+def layernorm_bwd(x, gamma, eps, dy, dx=None, *, accumulate=False):
+    xf = x.float()
+    mu = xf.mean(-1, keepdim=True)
+    r = torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + eps)
+    xh = (xf - mu) * r
+    g = gamma.float() * dy.float()
+    d = r * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if dx is None:
+        dx = d
+    elif accumulate:
+        dx += d
+    else:
+        dx.copy_(d)
+    return dx, (dy.float() * xh).sum(0), dy.float().sum(0)
+
+
+def swiglu(gu, out=None):
+    M, N2 = gu.shape
+    g = gu.float().view(M, N2 // 64, 2, 32)
+    return (F.silu(g[:, :, 0]) * g[:, :, 1]).reshape(M, N2 // 2).to(gu.dtype)
+
+
+def swiglu_bwd(gu, dg, out=None):
+    M, N2 = gu.shape
+    g = gu.float().view(M, N2 // 64, 2, 32)
+    gate, up = g[:, :, 0], g[:, :, 1]
+    d = dg.float().view(M, N2 // 64, 32)
+    sg = torch.sigmoid(gate)
+    dgate = d * up * sg * (1 + gate * (1 - sg))
+    dup = d * gate * sg
+    return torch.stack((dgate, dup), dim=2).reshape(M, N2).to(gu.dtype)
+
+
+def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
+    M, N = dqkv.shape
+    x = dqkv.float().view(M, N // 64, 2, 32)
+    grp = torch.arange(N // 64)
+    pos = torch.arange(M) % rope_seq
+    fi = (grp % 2)[:, None] * 32 + torch.arange(32)[None, :]
+    c, s = cos[pos][:, fi], sin[pos][:, fi]
+    live = (grp * 64 < rope_cols)[None, :, None]
+    d1, d2 = x[:, :, 0], x[:, :, 1]
+    x1 = torch.where(live, d1 * c + d2 * s, d1)
+    x2 = torch.where(live, d2 * c - d1 * s, d2)
+    dqkv.copy_(torch.stack((x1, x2), dim=2).reshape(M, N).to(dqkv.dtype))
+    return dqkv
+
+
+def attention_bwd(q, k, v, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
+                  d_strides=None):
+    def heads(t, given):
+        bs, rs = given if given is not None else (S * t.stride(0), t.stride(0))
+        return torch.as_strided(t, (B, S, H, D), (bs, rs, D, 1), t.storage_offset())
+    qh, kh, vh = (heads(t, strides).float().transpose(1, 2) for t in (q, k, v))
+    doh = heads(do, do_strides).float().transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(torch.ones(S, S).triu(1).bool(), float("-inf"))
+    if kv_len is not None:
+        dead = torch.arange(S)[None, :] >= kv_len.long()[:, None]
+        s = s.masked_fill(dead[:, None, None, :], float("-inf"))
+    p = s.softmax(-1)
+    gv = p.transpose(-1, -2) @ doh
+    dp = doh @ vh.transpose(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdim=True))
+    gq = (ds @ kh) * scale
+    gk = (ds.transpose(-1, -2) @ qh) * scale
+    for dst, val in ((dq, gq), (dk, gk), (dv, gv)):
+        heads(dst, d_strides).copy_(val.transpose(1, 2).to(dst.dtype))
+    return dq, dk, dv
+
+
+def cross_entropy_bwd(logits, labels, scale, *, dtype, vocab=None):
+    n, Vp = logits.shape
+    V = Vp if vocab is None else vocab
+    lab = labels.long()
+    pr = logits[:, :V].float().softmax(-1)
+    ok = lab >= 0
+    pr[ok, lab[ok]] -= 1.0
+    pr[~ok] = 0.0
+    out = torch.zeros((n, Vp), dtype=torch_dtype(dtype))
+    out[:, :V] = (pr * scale).to(out.dtype)
+    return out
+
+
+def scatter_add_rows(src, idx, dst_a, dst_b=None, scale=1.0):
+    i = idx.long()
+    pos = i >= 0
+    dst_a.index_add_(0, i[pos], src[: i.numel()][pos].float() * scale)
+    if (~pos).any():
+        dst_b.index_add_(0, -i[~pos] - 1, src[: i.numel()][~pos].float() * scale)
+
+
+def cosine_rows_bwd(a, b, idx_a=None, idx_b=None, n_rows=None, scale=1.0):
+    aa = a if idx_a is None else a[idx_a.long()]
+    bb = b if idx_b is None else b[idx_b.long()]
+    n = n_rows if n_rows is not None else aa.shape[0]
+    aa, bb = aa[:n].float(), bb[:n].float()
+    na = aa.norm(dim=-1, keepdim=True)
+    ah, bh = aa / na, F.normalize(bb, dim=-1)
+    return -2.0 * scale * (bh - (ah * bh).sum(-1, keepdim=True) * ah) / na
+
+
+def colsum(x):
+    return x.float().sum(0)
+
+
+def relu_bwd(dy, y):
+    return dy * (y > 0).to(dy.dtype)
+
+
+def bcast_add_t(dst, src, scale):
+    dst += scale * src.unsqueeze(1)
+
+
+def adamw(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p16=None):
+    gg = g * grad_scale
+    p.mul_(1 - lr * weight_decay)
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    denom = (v.sqrt() / math.sqrt(1 - beta2 ** step)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - beta1 ** step))
+    if p16 is not None:
+        p16.copy_(p)
+
+
+def sumsq(x, out=None):
+    if out is None:
+        out = torch.zeros(1)
+    out += x.float().pow(2).sum()
+    return out
+
+
 @contextlib.contextmanager
 def installed():
     """Monkey-patch stllm_amd.hip's compute entry points with the functions above (tests only)."""
     from stllm_amd import hip
     names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
-             "cross_entropy_rows", "cast_rows", "preprocess_frames"]
+             "cross_entropy_rows", "cast_rows", "preprocess_frames", "transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu",
+             "swiglu_bwd", "rope_bwd", "attention_bwd", "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum",
+             "relu_bwd", "bcast_add_t", "adamw", "sumsq"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

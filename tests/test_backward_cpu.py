@@ -76,3 +76,42 @@ def test_oracle_gradients_match_reference(tag):
     g, cfg, sd, samples = case_inputs(tag)
     loss, grads = oracle_grads(cfg, sd, samples)
     check_against_fixture(g, tag, loss, grads, 2e-4)
+
+
+# ---- the product's explicit backward graph on the test-only CPU backend ------------------------------------------------
+def product_samples(g, tag, text):
+    before = unragged(g[f"{tag}.before"])
+    qtext = unragged(g[f"{tag}.qtext"])
+    after_eff = unragged(g[f"{tag}.after"])
+    after = [a[1: len(a) - len(q)] for a, q in zip(after_eff, qtext)] if text else after_eff
+    answer = [a[:-1] for a in unragged(g[f"{tag}.answer"])]
+    s = lambda r: " ".join(map(str, r))
+    if text:
+        instr = [f"{s(before[i])}<ImageHere>{s(after[i])} Human: {s(qtext[i])} ###" for i in range(2)]
+    else:
+        instr = [f"{s(before[i])}<ImageHere>{s(after[i])}" for i in range(2)]
+    return instr, [s(a) for a in answer]
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_product_backward_matches_reference(tag):
+    """stllm_amd.training.loss_and_grads (host graph + kernel contracts of include/stllm_hip.h, restated in tests/_cpu_backend.py)
+    against the reference's gradients, fp32."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import build
+    from stllm_amd import runtime, training
+    g = golden("backward")
+    cfg, Tn = CASES[tag]
+    text = cfg["qformer_text_input"]
+    model = build(dict(cfg, image_size=224, num_query_token=32, max_txt_len=32, end_sym=" 2"), vit_depth=1, qf_layers=2, llm_layers=2)
+    instr, answers = product_samples(g, tag, text)
+    samples = {"image": T("input.video", (2, Tn, 3, 224, 224)), "instruction_input": instr, "answer": answers}
+    if cfg.get("use_mask"):
+        samples["mask"] = torch.from_numpy(g[f"{tag}.mask"])
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        loss, loss_mvm, grads = training.loss_and_grads(model, samples)
+        fwd = model(samples=samples)                       # the inference forward computes the same loss
+    assert abs(loss.item() - fwd.loss.item()) <= 2e-5 * max(1.0, abs(fwd.loss.item()))
+    check_against_fixture(g, tag, loss.item(), grads, 3e-4)
+    names = {n for n, _ in training.trainable_parameters(model)}
+    assert names == set(grads), names ^ set(grads)
