@@ -115,3 +115,30 @@ def test_product_backward_matches_reference(tag):
     check_against_fixture(g, tag, loss.item(), grads, 3e-4)
     names = {n for n, _ in training.trainable_parameters(model)}
     assert names == set(grads), names ^ set(grads)
+
+
+def test_mean_pooling_backward_and_one_optimizer_step():
+    """`video_input: mean` (not in the reference fixture) against autograd over the pinned oracle, then one AdamW step through
+    train_step: the masters alias the optimizer's flat buffer, packed copies are rebuilt, and the loss goes down."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build, make_inputs
+    from stllm_amd import runtime, training
+    cfg = CFGS["mean_pooling"]
+    model = build(cfg, vit_depth=1, qf_layers=2, llm_layers=1)
+    samples, osamples = make_inputs(2, 4, False)
+    sd = sd_from({**shapes.stllm_model_shapes(1, 2, False, "mean", False, qf_vocab=32000), **shapes.llama_shapes(1)})
+    want_loss, want = oracle_grads(cfg, sd, osamples)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        loss, _, grads = training.loss_and_grads(model, samples)
+        assert abs(loss.item() - want_loss) <= 1e-4
+        assert set(grads) == set(want)
+        for n, gr in grads.items():
+            scale = want[n].abs().max().item()
+            assert (gr - want[n]).abs().max().item() <= 3e-4 * scale, n
+        opt = training.AdamW(list(training.trainable_parameters(model)), lr=1e-3, max_grad_norm=1.0)
+        before = model.lm_head.weight.detach().clone()
+        l0, _, norm = training.train_step(model, samples, opt)
+        assert abs(l0.item() - want_loss) <= 1e-4 and norm > 0
+        assert not torch.equal(before, model.lm_head.weight)
+        l1 = model(samples=samples).loss
+    assert l1.item() < l0.item() - 0.05, (l0.item(), l1.item())
