@@ -209,6 +209,96 @@ int stllm_cross_entropy_rows(const float* logits, int64_t ldl, const int32_t* la
  * boundary of blip2.py:36-44, when a GEMM consumes rows of the fp32 stream without a norm in between. */
 int stllm_cast_rows(int dtype, const float* x, int64_t ldx, void* out, int64_t ldo, int M, int D, void* stream);
 
+/* =========================================================================================================================
+ * Backward / optimizer entry points.  The reference has no such code of its own: the gradients come
+ * from torch.autograd over st_llm.py:116-146 (shifted CE + loss_mvm) driven by HF Trainer + DeepSpeed (train_hf.py,
+ * stllm_trainer.py:317, config/(model)_stllm_qa.yaml: freeze_LLM False, bf16, AdamW lr 2e-5).  Each entry point below is the
+ * transpose (vector-Jacobian product) of one forward entry point above, with the same pointer / stride / stream conventions;
+ * GEMM-shaped gradients reuse stllm_gemm on operands re-laid-out by stllm_transpose:
+ *      y = x W^T :   dx = gemm(A = dy,   W = W^T [K, N])          dW = gemm(A = dy^T [N, Mp], W = x^T [K, Mp])  (fp32 out)
+ * ========================================================================================================================= */
+
+/* dst[c, r] = src[r, c] for r < rows, 0 for rows <= r < rows_padded (zero K-padding for the GEMM).  dtype sizes 2 or 4. */
+int stllm_transpose(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int cols, int rows_padded,
+                    void* stream);
+
+/* scratch of the two norm-backward entry points and of stllm_colsum: per-row statistics + column partial sums */
+int64_t stllm_norm_bwd_workspace_bytes(int rows, int cols);
+
+/* Transpose of stllm_rmsnorm (modeling_llama_mem.py:61-78): with r = rsqrt(mean(x^2) + eps), xh = x r, g = gamma * dy:
+ *   dx (+)= r * (g - xh * mean(g * xh))      dgamma[c] = sum_rows dy * xh       (dy: T_dy [rows, cols], T_dy any dtype code)
+ * accumulate != 0 adds into dx (the fp32 residual-stream gradient), else overwrites.  Deterministic (no atomics). */
+int stllm_rmsnorm_bwd(int dy_dtype, const float* x, int64_t ldx, const float* gamma, float eps, const void* dy, int64_t lddy,
+                      float* dx, int64_t lddx, int accumulate, float* dgamma, void* workspace, int64_t workspace_bytes, int rows,
+                      int cols, void* stream);
+
+/* Transpose of stllm_layernorm (st_llm.py:39 mvm_decoder.norm): xh = (x - mu) r;
+ *   dx (+)= r * (g - mean(g) - xh * mean(g * xh))      dgamma = sum dy * xh      dbeta = sum dy */
+int stllm_layernorm_bwd(int dy_dtype, const float* x, int64_t ldx, const float* gamma, float eps, const void* dy, int64_t lddy,
+                        float* dx, int64_t lddx, int accumulate, float* dgamma, float* dbeta, void* workspace,
+                        int64_t workspace_bytes, int rows, int cols, void* stream);
+
+/* SiLU(gate) * up on RAW gate/up activations in the packed [32 gate | 32 up] column groups of the SWIGLU epilogue
+ * (modeling_llama_mem.py:143-144).  Training keeps the raw activations (STORE epilogue) so the backward needs no
+ * recomputation:  gu T[rows, 2*inter] -> out T[rows, inter]. */
+int stllm_swiglu(int dtype, const void* gu, int64_t ldgu, void* out, int64_t ldo, int rows, int inter, void* stream);
+
+/* d gate = dg * up * s * (1 + gate * (1 - s)),  d up = dg * gate * s,  s = sigmoid(gate); output in the packed layout of gu. */
+int stllm_swiglu_bwd(int dtype, const void* gu, int64_t ldgu, const void* dg, int64_t lddg, void* dgu, int64_t lddgu, int rows,
+                     int inter, void* stream);
+
+/* Transpose of the ROPE epilogue's rotation, in place on the first rope_cols columns of d T[rows, cols] (packed head layout,
+ * position = row % rope_seq; cos/sin as for stllm_gemm):  dx1 = dy1 c + dy2 s,  dx2 = dy2 c - dy1 s. */
+int stllm_rope_bwd(int dtype, void* d, int64_t ld, const float* cos_t, const float* sin_t, int rows, int cols, int rope_seq,
+                   int rope_cols, void* stream);
+
+/* Gradients of stllm_attention for the Llama prefill (Sq == Skv == S, D == 128): dq, dk, dv from q, k, v, the forward output
+ * o and its gradient dO; same element addressing as stllm_attention for all eight operands; masks as in the forward.
+ * workspace: stllm_attention_bwd_workspace_bytes(B, H, S) (log-sum-exp and dO.o per query row). */
+int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int S);
+int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                        const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
+                        const void* dO, int64_t do_bs, int64_t do_rs, void* dq, int64_t dq_bs, int64_t dq_rs,
+                        void* dk, int64_t dk_bs, int64_t dk_rs, void* dv, int64_t dv_bs, int64_t dv_rs,
+                        int B, int H, int S, int D, float scale, int causal, const int32_t* kv_len,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Transpose of stllm_cross_entropy_rows summed with weight `scale` (st_llm.py:127-135; scale = 1 / #valid rows):
+ * dlogits[i, c] = scale * (softmax(logits[i, :vocab])[c] - [c == labels[i]]) for labels[i] >= 0, else 0; columns
+ * vocab .. cols_padded-1 (lm_head padding) are written as 0.  dlogits: T[rows, cols_padded]. */
+int stllm_cross_entropy_bwd(int dtype, const float* logits, int64_t ldl, const int32_t* labels, float scale, void* dlogits,
+                            int64_t lddl, int rows, int vocab, int cols_padded, void* stream);
+
+/* Transpose of stllm_gather_rows: (idx[i] >= 0 ? dst_a[idx[i]] : dst_b[-idx[i]-1]) += scale * src[i]  (fp32 atomics; rows that
+ * are hit more than once — repeated token ids — make the summation order, not the set of summands, run-dependent). */
+int stllm_scatter_add_rows(const float* src, int64_t ld_src, const int32_t* idx, float* dst_a, int64_t ld_a, float* dst_b,
+                           int64_t ld_b, int n_rows, int D, float scale, void* stream);
+
+/* d/da of  scale * sum_i stllm_cosine_rows(a, b)[i]  (st_llm.py:89-91; b is the detached target):
+ * da[i] = -2 scale / |a_i| * (b_i/|b_i| - cos_i * a_i/|a_i|),  rows gathered by index as in the forward. */
+int stllm_cosine_rows_bwd(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb, const int32_t* idx_b,
+                          float scale, float* da, int64_t ldda, int n_rows, int D, void* stream);
+
+/* out[c] = sum_rows x[r, c]  (bias gradients); workspace: stllm_norm_bwd_workspace_bytes(rows, cols).  Deterministic. */
+int stllm_colsum(int dtype, const void* x, int64_t ldx, float* out, int rows, int cols, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* dx = dy * (y > 0)  — the ReLU between down_proj and up_proj (st_llm.py:473-475); cols % 8 == 0. */
+int stllm_relu_bwd(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, void* dx, int64_t lddx, int rows, int cols,
+                   void* stream);
+
+/* Transpose of stllm_mean_t up to the 1/T factor: dst[b, t, j] += scale * src[b, j]  (f32, J % 4 == 0). */
+int stllm_bcast_add_t(float* dst, const float* src, int B, int T, int64_t J, float scale, void* stream);
+
+/* torch.optim.AdamW step on flat fp32 state (what HF Trainer instantiates for the reference's runs):
+ *   g' = grad_scale * g;  p *= 1 - lr * weight_decay;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps);   p16 (optional, dtype code p16_dtype) = cast(p). */
+int stllm_adamw(float* p, const float* g, float* m, float* v, void* p16, int p16_dtype, int64_t n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* out[0] += sum x^2  (gradient-norm clipping, torch.nn.utils.clip_grad_norm_); the caller zeroes out[0]. */
+int stllm_sumsq(const float* x, int64_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,329 @@
+// Attention backward for the training step: gradients of  O = softmax(scale * Q K^T + masks) V
+// for head_dim 128, causal and / or key-length masked (right-padded batches), operands in the strided fused-QKV layout of
+// the forward kernels (include/stllm_hip.h: element (b, s, h, d) at base[b * batch_stride + s * row_stride + h * D + d]).
+//
+// Flash-attention-2 backward structure, three kernels, nothing S x S ever touches HBM:
+//   1. stats: per query row  lse = log sum_j exp(s_ij),  delta = dO_i . O_i                (workspace, 8 bytes per row)
+//   2. dq   : one workgroup per 32 queries, sweeps the visible key tiles: P = exp(s - lse), dS = P * (dO V^T - delta),
+//             dQ = scale * dS K
+//   3. dkv  : one workgroup per 32 keys, sweeps the query tiles that see them: dV = P^T dO,  dK = scale * dS^T Q
+// Tiles are staged in LDS as fp32 (row stride 132 floats: the float4 reads of 8 consecutive rows hit 32 distinct banks).
+// FIRST VERSION: the 32x32x128 tile products run on the VALU (fp32 FMA) — correct for bf16 / f16 / f32 operands alike and
+// simple enough to validate; the MFMA version (same tiling, 32x32x16 MFMA on 16-bit tiles) replaces the inner products once
+// this one is parity-green on the device.  Algorithmic FLOPs: 5 * 2 * S^2/2 * 128 per (b, h) for causal masks.
+#include "common.h"
+
+namespace {
+
+constexpr int kD = 128;       // head dim
+constexpr int kT = 32;        // tile edge (queries / keys)
+constexpr int kLd = 132;      // LDS row stride in floats
+constexpr int kTile = kT * kLd;
+
+template <typename T> __device__ __forceinline__ void ld8(const void* base, int64_t idx, float* f) {
+  if constexpr (Elem<T>::kIsF32) {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+    const float4 a = p[0], b = p[1];
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f[2 * e] = Elem<T>::unpack((uint16_t)(w[e] & 0xffffu));
+      f[2 * e + 1] = Elem<T>::unpack((uint16_t)(w[e] >> 16));
+    }
+  }
+}
+template <typename T> __device__ __forceinline__ void st8(void* base, int64_t idx, const float* f) {
+  if constexpr (Elem<T>::kIsF32) {
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx);
+    p[0] = make_float4(f[0], f[1], f[2], f[3]);
+    p[1] = make_float4(f[4], f[5], f[6], f[7]);
+  } else {
+    uint4 u;
+    u.x = Elem<T>::pack2(f[0], f[1]); u.y = Elem<T>::pack2(f[2], f[3]);
+    u.z = Elem<T>::pack2(f[4], f[5]); u.w = Elem<T>::pack2(f[6], f[7]);
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + idx) = u;
+  }
+}
+
+struct Ptr { const void* p; int64_t bs, rs; };
+struct MPtr { void* p; int64_t bs, rs; };
+
+// rows [row0, row0 + 32) of head (b, h) -> lds[32][kLd] as fp32, zero beyond S
+template <typename T>
+__device__ __forceinline__ void load_tile(float* lds, const Ptr& t, int b, int h, int row0, int S, int tid) {
+  const int64_t off = (int64_t)b * t.bs + (int64_t)h * kD;
+  for (int v = tid; v < kT * (kD / 8); v += 256) {
+    const int r = v >> 4, c = (v & 15) * 8;
+    float f[8];
+    if (row0 + r < S) ld8<T>(t.p, off + (int64_t)(row0 + r) * t.rs + c, f);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.0f;
+    }
+    float4* d = reinterpret_cast<float4*>(lds + r * kLd + c);
+    d[0] = make_float4(f[0], f[1], f[2], f[3]);
+    d[1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+}
+
+__device__ __forceinline__ float dot128(const float* a, const float* b) {
+  float s = 0.0f;
+#pragma unroll 8
+  for (int d = 0; d < kD; d += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(a + d), y = *reinterpret_cast<const float4*>(b + d);
+    s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+  }
+  return s;
+}
+__device__ __forceinline__ float oct_sum(float v) {   // over the 8 consecutive lanes that share a row
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ float oct_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+  return v;
+}
+
+// ---- 1. statistics -------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(Ptr q, Ptr k, Ptr o, Ptr dO, float* __restrict__ ws, int H, int S, float scale,
+                                                             int causal, const int32_t* __restrict__ kv_len) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Ks = smem + kTile;
+  const int tid = threadIdx.x, qi = tid >> 3, kg = tid & 7;
+  const int q0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
+  const int kmax = kv_len ? min(S, kv_len[b]) : S;
+  const int kend = causal ? min(kmax, q0 + kT) : kmax;
+  load_tile<T>(Qs, q, b, h, q0, S, tid);
+  float m = -3.0e38f, l = 0.0f;
+  for (int k0 = 0; k0 < kend; k0 += kT) {
+    __syncthreads();
+    load_tile<T>(Ks, k, b, h, k0, S, tid);
+    __syncthreads();
+    float s[4], mt = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kj = kg * 4 + t, kk = k0 + kj;
+      const bool ok = kk < kend && (!causal || kk <= q0 + qi);
+      s[t] = ok ? dot128(Qs + qi * kLd, Ks + kj * kLd) * scale : -3.0e38f;
+      mt = fmaxf(mt, s[t]);
+    }
+    mt = oct_max(mt);
+    const float mn = fmaxf(m, mt);
+    float ps = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ps += s[t] > -1.0e38f ? __expf(s[t] - mn) : 0.0f;
+    ps = oct_sum(ps);
+    if (mn > -1.0e38f) { l = l * __expf(m - mn) + ps; m = mn; }
+  }
+  // delta = dO . O over this thread's 16 of the 128 dims
+  float dl = 0.0f;
+  if (q0 + qi < S) {
+    const int64_t oo = (int64_t)b * o.bs + (int64_t)(q0 + qi) * o.rs + (int64_t)h * kD + kg * 16;
+    const int64_t od = (int64_t)b * dO.bs + (int64_t)(q0 + qi) * dO.rs + (int64_t)h * kD + kg * 16;
+    float a[8], c[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      ld8<T>(o.p, oo + half * 8, a);
+      ld8<T>(dO.p, od + half * 8, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl = fmaf(a[e], c[e], dl);
+    }
+  }
+  dl = oct_sum(dl);
+  if (kg == 0 && q0 + qi < S) {
+    float* w = ws + ((int64_t)(b * H + h) * S + q0 + qi) * 2;
+    w[0] = m + __logf(l);
+    w[1] = dl;
+  }
+}
+
+// ---- 2. dQ -----------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dq, const float* __restrict__ ws, int H, int S,
+                                                          float scale, int causal, const int32_t* __restrict__ kv_len) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Os = smem + kTile;
+  float* Ks = smem + 2 * kTile;
+  float* Vs = smem + 3 * kTile;
+  float* Ds = smem + 4 * kTile;            // [32][33]
+  const int tid = threadIdx.x, qi = tid >> 3, kg = tid & 7;
+  const int q0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
+  const int kmax = kv_len ? min(S, kv_len[b]) : S;
+  const int kend = causal ? min(kmax, q0 + kT) : kmax;
+  load_tile<T>(Qs, q, b, h, q0, S, tid);
+  load_tile<T>(Os, dO, b, h, q0, S, tid);
+  float lse = 0.0f, delta = 0.0f;
+  if (q0 + qi < S) {
+    const float* w = ws + ((int64_t)(b * H + h) * S + q0 + qi) * 2;
+    lse = w[0]; delta = w[1];
+  }
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  for (int k0 = 0; k0 < kend; k0 += kT) {
+    __syncthreads();
+    load_tile<T>(Ks, k, b, h, k0, S, tid);
+    load_tile<T>(Vs, v, b, h, k0, S, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kj = kg * 4 + t, kk = k0 + kj;
+      const bool ok = kk < kend && (!causal || kk <= q0 + qi) && q0 + qi < S;
+      float ds = 0.0f;
+      if (ok) {
+        const float s = dot128(Qs + qi * kLd, Ks + kj * kLd) * scale;
+        const float dp = dot128(Os + qi * kLd, Vs + kj * kLd);
+        ds = __expf(s - lse) * (dp - delta);
+      }
+      Ds[qi * 33 + kj] = ds;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < kT; ++j) {
+      const float w = Ds[qi * 33 + j];
+      const float* kr = Ks + j * kLd + kg * 16;
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(kr + e);
+        acc[e] = fmaf(w, x.x, acc[e]); acc[e + 1] = fmaf(w, x.y, acc[e + 1]);
+        acc[e + 2] = fmaf(w, x.z, acc[e + 2]); acc[e + 3] = fmaf(w, x.w, acc[e + 3]);
+      }
+    }
+  }
+  if (q0 + qi < S) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] *= scale;
+    const int64_t off = (int64_t)b * dq.bs + (int64_t)(q0 + qi) * dq.rs + (int64_t)h * kD + kg * 16;
+    st8<T>(dq.p, off, acc);
+    st8<T>(dq.p, off + 8, acc + 8);
+  }
+}
+
+// ---- 3. dK, dV ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws, int H,
+                                                           int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Os = smem + kTile;
+  float* Ks = smem + 2 * kTile;
+  float* Vs = smem + 3 * kTile;
+  float* Ps = smem + 4 * kTile;            // [32 q][33]
+  float* Ds = Ps + kT * 33;                // [32 q][33]
+  const int tid = threadIdx.x, kj = tid >> 3, qg = tid & 7;
+  const int k0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
+  const int kmax = kv_len ? min(S, kv_len[b]) : S;
+  const int kk = k0 + kj;
+  load_tile<T>(Ks, k, b, h, k0, S, tid);
+  load_tile<T>(Vs, v, b, h, k0, S, tid);
+  float av[16], ak[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) av[e] = ak[e] = 0.0f;
+  const float* wrow = ws + (int64_t)(b * H + h) * S * 2;
+  for (int q0 = causal ? k0 : 0; q0 < S; q0 += kT) {
+    __syncthreads();
+    load_tile<T>(Qs, q, b, h, q0, S, tid);
+    load_tile<T>(Os, dO, b, h, q0, S, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qi = qg * 4 + t, qq = q0 + qi;
+      const bool ok = qq < S && kk < kmax && (!causal || kk <= qq);
+      float p = 0.0f, ds = 0.0f;
+      if (ok) {
+        const float s = dot128(Qs + qi * kLd, Ks + kj * kLd) * scale;
+        const float dp = dot128(Os + qi * kLd, Vs + kj * kLd);
+        p = __expf(s - wrow[2 * qq]);
+        ds = p * (dp - wrow[2 * qq + 1]);
+      }
+      Ps[qi * 33 + kj] = p;
+      Ds[qi * 33 + kj] = ds;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int i = 0; i < kT; ++i) {
+      const float p = Ps[i * 33 + kj], ds = Ds[i * 33 + kj];
+      const float* orow = Os + i * kLd + qg * 16;
+      const float* qrow = Qs + i * kLd + qg * 16;
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(orow + e), y = *reinterpret_cast<const float4*>(qrow + e);
+        av[e] = fmaf(p, x.x, av[e]); av[e + 1] = fmaf(p, x.y, av[e + 1]); av[e + 2] = fmaf(p, x.z, av[e + 2]); av[e + 3] = fmaf(p, x.w, av[e + 3]);
+        ak[e] = fmaf(ds, y.x, ak[e]); ak[e + 1] = fmaf(ds, y.y, ak[e + 1]); ak[e + 2] = fmaf(ds, y.z, ak[e + 2]); ak[e + 3] = fmaf(ds, y.w, ak[e + 3]);
+      }
+    }
+  }
+  if (kk < S) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ak[e] *= scale;
+    const int64_t ok_ = (int64_t)b * dk.bs + (int64_t)kk * dk.rs + (int64_t)h * kD + qg * 16;
+    const int64_t ov_ = (int64_t)b * dv.bs + (int64_t)kk * dv.rs + (int64_t)h * kD + qg * 16;
+    st8<T>(dk.p, ok_, ak);
+    st8<T>(dk.p, ok_ + 8, ak + 8);
+    st8<T>(dv.p, ov_, av);
+    st8<T>(dv.p, ov_ + 8, av + 8);
+  }
+}
+
+constexpr int kLdsStats = 2 * kTile * 4;
+constexpr int kLdsDq = (4 * kTile + kT * 33) * 4;
+constexpr int kLdsDkv = (4 * kTile + 2 * kT * 33) * 4;
+
+template <typename T>
+int launch_bwd(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, float scale, int causal,
+               const int32_t* kv_len, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDq) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDkv) != hipSuccess) {
+      stllm_set_error("stllm_attention_bwd: cannot raise the dynamic LDS limit");
+      return STLLM_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const dim3 grid((S + kT - 1) / kT, H, B), block(256);
+  hipLaunchKernelGGL(attn_bwd_stats_kernel<T>, grid, block, kLdsStats, st, q, k, o, dO, ws, H, S, scale, causal, kv_len);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, block, kLdsDq, st, q, k, v, dO, dq, ws, H, S, scale, causal, kv_len);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, block, kLdsDkv, st, q, k, v, dO, dk, dv, ws, H, S, scale, causal, kv_len);
+  return STLLM_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int S) { return (int64_t)B * H * S * 2 * 4; }
+
+extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                                   int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs, const void* dO, int64_t do_bs,
+                                   int64_t do_rs, void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs, void* dv,
+                                   int64_t dv_bs, int64_t dv_rs, int B, int H, int S, int D, float scale, int causal, const int32_t* kv_len,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+  STLLM_CHECK_ARG(q && k && v && o && dO && dq && dk && dv && B > 0 && H > 0 && S > 0, "stllm_attention_bwd: bad args");
+  STLLM_CHECK_ARG(D == kD, "stllm_attention_bwd: head_dim %d unsupported (128 only: the Llama heads)", D);
+  STLLM_CHECK_ARG(workspace && workspace_bytes >= stllm_attention_bwd_workspace_bytes(B, H, S), "stllm_attention_bwd: workspace too small");
+  const int eb = dtype == STLLM_F32 ? 4 : 2;
+  const void* ps[8] = {q, k, v, o, dO, dq, dk, dv};
+  const int64_t st_[16] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs};
+  for (int i = 0; i < 8; ++i)
+    STLLM_CHECK_ARG(aligned16(ps[i]) && (st_[2 * i] * eb) % 16 == 0 && (st_[2 * i + 1] * eb) % 16 == 0,
+                    "stllm_attention_bwd: operand %d must be 16-byte aligned with 16-byte-multiple strides", i);
+  const Ptr Q{q, q_bs, q_rs}, K{k, k_bs, k_rs}, V{v, v_bs, v_rs}, O{o, o_bs, o_rs}, DO{dO, do_bs, do_rs};
+  const MPtr DQ{dq, dq_bs, dq_rs}, DK{dk, dk_bs, dk_rs}, DV{dv, dv_bs, dv_rs};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float* ws = reinterpret_cast<float*>(workspace);
+  int rc;
+  switch (dtype) {
+    case STLLM_BF16: rc = launch_bwd<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    case STLLM_F16: rc = launch_bwd<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    case STLLM_F32: rc = launch_bwd<float>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    default: stllm_set_error("stllm_attention_bwd: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;
+  }
+  if (rc != STLLM_OK) return rc;
+  STLLM_CHECK_LAUNCH("stllm_attention_bwd");
+  return STLLM_OK;
+}

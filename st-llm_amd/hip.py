@@ -380,7 +380,7 @@ def set_option(key, value):
 # Training entry points (include/stllm_hip.h "backward / optimizer").  Same rules: device pointers,
 # current stream, no fallback.
 TRAIN_EXPORTS = ["stllm_transpose", "stllm_norm_bwd_workspace_bytes", "stllm_rmsnorm_bwd", "stllm_layernorm_bwd", "stllm_swiglu",
-                 "stllm_swiglu_bwd", "stllm_rope_bwd", "stllm_attention_bwd", "stllm_cross_entropy_bwd", "stllm_scatter_add_rows",
+                 "stllm_swiglu_bwd", "stllm_rope_bwd", "stllm_attention_bwd_workspace_bytes", "stllm_attention_bwd", "stllm_cross_entropy_bwd", "stllm_scatter_add_rows",
                  "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
@@ -399,7 +399,9 @@ def _tlib():
         L.stllm_swiglu.argtypes = [i, p, i64, p, i64, i, i, p]
         L.stllm_swiglu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
         L.stllm_rope_bwd.argtypes = [i, p, i64, p, p, i, i, i, i, p]
-        L.stllm_attention_bwd.argtypes = [i] + [p, i64, i64] * 7 + [i, i, i, i, f, i, p, p]
+        L.stllm_attention_bwd_workspace_bytes.restype = c_int64
+        L.stllm_attention_bwd_workspace_bytes.argtypes = [i, i, i]
+        L.stllm_attention_bwd.argtypes = [i] + [p, i64, i64] * 8 + [i, i, i, i, f, i, p, p, i64, p]
         L.stllm_cross_entropy_bwd.argtypes = [i, p, i64, p, f, p, i64, i, i, i, p]
         L.stllm_scatter_add_rows.argtypes = [p, i64, p, p, i64, p, i64, i, i, f, p]
         L.stllm_cosine_rows_bwd.argtypes = [p, i64, p, p, i64, p, f, p, i64, i, i, p]
@@ -409,7 +411,7 @@ def _tlib():
         L.stllm_adamw.argtypes = [p, p, p, p, p, i, i64, f, f, f, f, f, i, f, p]
         L.stllm_sumsq.argtypes = [p, i64, p, p]
         for n in TRAIN_EXPORTS:
-            if n != "stllm_norm_bwd_workspace_bytes":
+            if not n.endswith("_workspace_bytes"):
                 getattr(L, n).restype = c_int
         _train_bound = True
     return L
@@ -489,10 +491,10 @@ def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
     return dqkv
 
 
-def attention_bwd(q, k, v, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
+def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
                   d_strides=None):
-    """Gradients of softmax(scale * q k^T + masks) v.  q/k/v/dq/dk/dv: 2-D views of the compute dtype as in `attention`
-    (strides = (batch_stride, row_stride) in elements, shared by q, k, v; d_strides by dq, dk, dv); do [B*S, H*D]."""
+    """Gradients of o = softmax(scale * q k^T + masks) v.  q/k/v/dq/dk/dv: 2-D views of the compute dtype as in `attention`
+    (strides = (batch_stride, row_stride) in elements, shared by q, k, v; d_strides by dq, dk, dv); o, do [B*S, H*D]."""
     td = q.dtype
 
     def st(t, given):
@@ -501,9 +503,11 @@ def attention_bwd(q, k, v, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv
     if kv_len is not None:
         _req(kv_len, torch.int32, "kv_len")
     a = [dtype_code(td)]
-    for t, ss in ((q, s_), (k, s_), (v, s_), (do, os_), (dq, ds_), (dk, ds_), (dv, ds_)):
+    for t, ss in ((q, s_), (k, s_), (v, s_), (o, os_), (do, os_), (dq, ds_), (dk, ds_), (dv, ds_)):
         a += [_p(t), ss[0], ss[1]]
-    _check(_tlib().stllm_attention_bwd(*a, B, H, S, D, scale, int(causal), _p(kv_len), _stream()), "stllm_attention_bwd")
+    need = int(_tlib().stllm_attention_bwd_workspace_bytes(B, H, S))
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+    _check(_tlib().stllm_attention_bwd(*a, B, H, S, D, scale, int(causal), _p(kv_len), _p(ws), need, _stream()), "stllm_attention_bwd")
     return dq, dk, dv
 
 

@@ -159,7 +159,7 @@ def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model."):
         grads[lp + "self_attn.o_proj.weight"] = dw
         qkv = rec["qkv"]
         dqkv = torch.empty_like(qkv)
-        hip.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], da, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+        hip.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], rec["a"], da, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
                           B=B, H=H, S=S, D=hd, scale=hd ** -0.5, causal=True, kv_len=tape.kv_len)
         hip.rope_bwd(dqkv, tape.cos, tape.sin, rope_seq=S, rope_cols=2 * D)
         dh1, dw = linear_bwd(dqkv, rec["h1"], pk["wqkv"], dt)

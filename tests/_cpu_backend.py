@@ -235,7 +235,7 @@ def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
     return dqkv
 
 
-def attention_bwd(q, k, v, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
+def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
                   d_strides=None):
     def heads(t, given):
         bs, rs = given if given is not None else (S * t.stride(0), t.stride(0))

@@ -1,0 +1,75 @@
+"""TEST-ONLY: route stllm_amd.hip's *training* bindings to the host-emulated build of the same kernel sources
+(tests/hipemu): the ctypes argument lists of hip.py and the kernels' logic are then exercised on CPU tensors."""
+import contextlib
+import ctypes
+import importlib.util
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _builder():
+    spec = importlib.util.spec_from_file_location("build_emu", os.path.join(HERE, "hipemu", "build_emu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+ON_DEVICE = os.environ.get("STLLM_TRAIN_KERNELS_ON_DEVICE") == "1"   # set by tests/test_train_gpu.py for its child process
+
+
+def available():
+    return ON_DEVICE or os.path.exists(_builder().CLANG)
+
+
+class _DeviceProxy:
+    """stllm_amd.hip on the real GPU for tests written against CPU tensors: tensor arguments are copied to the device, the real
+    entry point runs, every tensor argument is copied back (in-place results) and tensor results are returned on the CPU."""
+
+    def __init__(self, hip):
+        self._hip = hip
+
+    def __getattr__(self, name):
+        import torch
+        f = getattr(self._hip, name)
+
+        def call(*a, **k):
+            moved = []
+
+            def mv(x):
+                if isinstance(x, torch.Tensor):
+                    y = x.cuda()
+                    moved.append((x, y))
+                    return y
+                return x
+
+            def back(r):
+                if isinstance(r, torch.Tensor):
+                    return r.cpu()
+                if isinstance(r, (tuple, list)):
+                    return type(r)(back(x) for x in r)
+                return r
+            r = f(*[mv(x) for x in a], **{kk: mv(v) for kk, v in k.items()})
+            torch.cuda.synchronize()
+            for x, y in moved:
+                x.copy_(y.cpu())
+            return back(r)
+        return call
+
+
+@contextlib.contextmanager
+def emulated():
+    from stllm_amd import hip
+    if ON_DEVICE:
+        yield _DeviceProxy(hip)
+        return
+    L = ctypes.CDLL(_builder().build())
+    L.stllm_last_error.restype = ctypes.c_char_p
+    saved = (hip._lib, hip._train_bound, hip._stream, hip._req)
+    hip._lib, hip._train_bound = L, False
+    hip._stream = lambda: None
+    hip._req = lambda t, dtype=None, what="tensor": t
+    try:
+        yield hip
+    finally:
+        hip._lib, hip._train_bound, hip._stream, hip._req = saved

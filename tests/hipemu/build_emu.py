@@ -1,0 +1,40 @@
+"""Build tests/hipemu/_build/libstllm_emu.so: the training kernels of st-llm_amd/csrc compiled for the HOST against the
+emulation shim (tests/hipemu/hip/hip_runtime.h).  Test infrastructure only (see the shim's header)."""
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip"]
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+DYN = "#include <hip/hip_runtime.h>\nnamespace { alignas(16) float smem[32768]; }\n"
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    lib = os.path.join(OUT, "libstllm_emu.so")
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h")]
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
+        return lib
+    tus = []
+    for f in KERNEL_SOURCES:
+        text = open(os.path.join(CSRC, f)).read()
+        dyn = "extern __shared__" in text
+        text = re.sub(r"extern\s+__shared__", "EMU_DYN_SHARED", text)
+        tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
+        with open(tu, "w") as fh:
+            fh.write((DYN if dyn else "") + text)
+        tus.append(tu)
+    cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
+           "-I", HERE, "-I", CSRC] + tus + [os.path.join(CSRC, "error.cpp"), "-o", lib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("emulation build failed:\n" + r.stderr[-4000:])
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force=True))

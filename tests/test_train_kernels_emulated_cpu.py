@@ -1,0 +1,233 @@
+"""CPU: the training kernels of st-llm_amd/csrc/{train_ops,attention_bwd}.hip, compiled for the host against the HIP emulation
+shim (tests/hipemu: one OS thread per HIP thread, real barriers and wave shuffles) and called through the SAME ctypes bindings
+as on the device (stllm_amd.hip), compared with the contract restatement in tests/_cpu_backend.py.  This checks indexing,
+masks, reductions, barrier structure and the argument lists — not performance and not ISA-level behaviour; the on-device
+parity tests are tests/test_train_gpu.py.  Tolerances: fp32 1e-5 of the tensor's abs-max; 16-bit outputs one rounding step
+(bf16 2^-8, f16 2^-11 relative to abs-max, plus the same for 16-bit inputs already rounded identically on both sides)."""
+import math
+
+import pytest
+import torch
+
+import _cpu_backend as C
+import _hipemu
+
+pytestmark = pytest.mark.skipif(not _hipemu.available(), reason="ROCm clang++ not found: cannot build the emulated kernels")
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+
+
+def rnd(*shape, seed=0, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(got, want, tol, what=""):
+    got, want = got.float(), want.float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{what}: err {err:.3e} vs abs-max {scale:.3e} (tol {tol:g})"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_zero_pads(dtype):
+    x = rnd(70, 133, dtype=dtype)[:, :130]            # row-strided view, ragged vs the 64x64 tiles
+    with _hipemu.emulated() as hip:
+        got = hip.transpose(x, pad=64)
+    assert got.shape == (130, 128) and torch.equal(got, C.transpose(x, pad=64))
+
+
+@pytest.mark.parametrize("dy_dtype", DTYPES)
+@pytest.mark.parametrize("accumulate", [True, False])
+def test_rmsnorm_bwd(dy_dtype, accumulate):
+    M, D = 37, 264
+    x, gamma, dy = rnd(M, D, seed=1), rnd(D, seed=2) + 1.0, rnd(M, D, seed=3, dtype=dy_dtype)
+    dx0 = rnd(M, D, seed=4)
+    want_dx = dx0.clone()
+    want_g = C.rmsnorm_bwd(x, gamma, 1e-6, dy, want_dx, accumulate=accumulate)
+    got_dx = dx0.clone()
+    with _hipemu.emulated() as hip:
+        got_g = hip.rmsnorm_bwd(x, gamma, 1e-6, dy, got_dx, accumulate=accumulate)
+    close(got_dx, want_dx, 1e-5, "dx")
+    close(got_g, want_g, 1e-5, "dgamma")
+
+
+@pytest.mark.parametrize("dy_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd(dy_dtype):
+    M, D = 41, 132
+    x, gamma, dy = rnd(M, D, seed=5) * 2 + 0.3, rnd(D, seed=6) + 1.0, rnd(M, D, seed=7, dtype=dy_dtype)
+    want = C.layernorm_bwd(x, gamma, 1e-5, dy)
+    with _hipemu.emulated() as hip:
+        got = hip.layernorm_bwd(x, gamma, 1e-5, dy)
+    for g, w, n in zip(got, want, ("dx", "dgamma", "dbeta")):
+        close(g, w, 1e-5, n)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swiglu_and_backward(dtype):
+    M, I = 9, 96
+    gu, dg = rnd(M, 2 * I, seed=8, dtype=dtype), rnd(M, I, seed=9, dtype=dtype)
+    with _hipemu.emulated() as hip:
+        g, dgu = hip.swiglu(gu), hip.swiglu_bwd(gu, dg)
+    close(g, C.swiglu(gu), TOL[dtype], "swiglu")
+    close(dgu, C.swiglu_bwd(gu, dg), TOL[dtype], "swiglu_bwd")
+    # ... and the packed layout really is the SWIGLU epilogue's: compare with the forward contract of stllm_gemm
+    eye = torch.eye(2 * I)
+    fused = C.gemm(gu.float(), eye, dtype=torch.float32, epilogue=C.EPI_SWIGLU)
+    close(g, fused, TOL[dtype], "swiglu vs epilogue")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope_bwd_is_the_transpose_of_the_epilogue(dtype):
+    from stllm_amd import pack
+    S, B, N = 5, 2, 384                                   # [q | k | v] of one 128-wide head
+    cos, sin = pack.rope_tables(S, 128)
+    d = rnd(B * S, N, seed=10, dtype=dtype)
+    want = C.rope_bwd(d.clone(), cos, sin, rope_seq=S, rope_cols=256)
+    got = d.clone()
+    with _hipemu.emulated() as hip:
+        hip.rope_bwd(got, cos, sin, rope_seq=S, rope_cols=256)
+    close(got, want, TOL[dtype], "rope_bwd")
+    assert torch.equal(got[:, 256:], d[:, 256:])
+    # <R x, y> == <x, R^T y> with R the forward epilogue (fp32)
+    x, y = rnd(B * S, N, seed=11), rnd(B * S, N, seed=12)
+    Rx = C.gemm(x, torch.eye(N), dtype=torch.float32, epilogue=C.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=256)
+    Rty = C.rope_bwd(y.clone(), cos, sin, rope_seq=S, rope_cols=256)
+    assert abs((Rx * y).sum().item() - (x * Rty).sum().item()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("causal,lens", [(True, None), (True, [70, 45]), (False, [33, 70])])
+def test_attention_bwd(dtype, causal, lens):
+    B, H, S, D = 2, 2, 70, 128                            # 3 tiles of 32, ragged
+    HD = H * D
+    qkv = rnd(B * S, 3 * HD, seed=13, dtype=dtype, scale=0.7)
+    do = rnd(B * S, HD, seed=14, dtype=dtype)
+    kv_len = None if lens is None else torch.tensor(lens, dtype=torch.int32)
+    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+    o = C.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5, causal=causal, kv_len=kv_len)
+    want = torch.zeros_like(qkv)
+    C.attention_bwd(q, k, v, o, do, want[:, :HD], want[:, HD:2 * HD], want[:, 2 * HD:], B=B, H=H, S=S, D=D, scale=D ** -0.5,
+                    causal=causal, kv_len=kv_len)
+    got = torch.full_like(qkv, float("nan"))
+    with _hipemu.emulated() as hip:
+        hip.attention_bwd(q, k, v, o, do, got[:, :HD], got[:, HD:2 * HD], got[:, 2 * HD:], B=B, H=H, S=S, D=D, scale=D ** -0.5,
+                          causal=causal, kv_len=kv_len)
+    assert not torch.isnan(got.float()).any()
+    for j, n in enumerate(("dq", "dk", "dv")):
+        # delta = dO.o uses the ROUNDED o on the device side as here; 16-bit: one rounding of the result + accumulated input rounding
+        close(got[:, j * HD:(j + 1) * HD], want[:, j * HD:(j + 1) * HD], 4 * TOL[dtype] if dtype != torch.float32 else 2e-5, n)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy_bwd(dtype):
+    n, V, Vp = 6, 300, 384
+    logits = rnd(n, Vp, seed=15, scale=3.0)
+    labels = torch.tensor([5, -100, 299, 0, -100, 17], dtype=torch.int32)
+    with _hipemu.emulated() as hip:
+        got = hip.cross_entropy_bwd(logits, labels, 0.25, dtype=dtype, vocab=V)
+    want = C.cross_entropy_bwd(logits, labels, 0.25, dtype=dtype, vocab=V)
+    close(got, want, TOL[dtype], "dlogits")
+    assert not got[:, V:].float().abs().max() and not got[1].float().abs().max()
+
+
+def test_scatter_add_rows_both_destinations_and_repeats():
+    src = rnd(7, 36, seed=16)
+    idx = torch.tensor([0, 3, -1, 3, -5, 2, -1], dtype=torch.int32)
+    a0, b0 = rnd(4, 36, seed=17), rnd(6, 36, seed=18)
+    wa, wb = a0.clone(), b0.clone()
+    C.scatter_add_rows(src, idx, wa, wb, scale=0.5)
+    ga, gb = a0.clone(), b0.clone()
+    with _hipemu.emulated() as hip:
+        hip.scatter_add_rows(src, idx, ga, gb, scale=0.5)
+    close(ga, wa, 1e-6, "dst_a")
+    close(gb, wb, 1e-6, "dst_b")
+
+
+def test_cosine_rows_bwd_matches_autograd():
+    a, b = rnd(9, 64, seed=19), rnd(20, 64, seed=20)
+    idx_b = torch.tensor([3, 1, 4, 1, 5, 9, 2, 6, 19], dtype=torch.int32)
+    with _hipemu.emulated() as hip:
+        got = hip.cosine_rows_bwd(a, b, None, idx_b, n_rows=9, scale=1.0 / 9)
+    av = a.clone().requires_grad_(True)
+    with torch.enable_grad():
+        C.cosine_rows(av, b, None, idx_b, n_rows=9).mean().backward()
+    close(got, av.grad, 1e-5, "da")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_relu_bwd(dtype):
+    x = rnd(203, 72, seed=21, dtype=dtype)
+    y = rnd(203, 72, seed=22, dtype=dtype)
+    with _hipemu.emulated() as hip:
+        cs, rb = hip.colsum(x), hip.relu_bwd(x, y)
+    close(cs, C.colsum(x), 1e-5, "colsum")
+    assert torch.equal(rb, C.relu_bwd(x, y))
+
+
+def test_bcast_add_t():
+    dst, src = rnd(2, 3, 40, seed=23), rnd(2, 40, seed=24)
+    want = dst.clone()
+    C.bcast_add_t(want, src, 1 / 3)
+    with _hipemu.emulated() as hip:
+        hip.bcast_add_t(dst, src, 1 / 3)
+    close(dst, want, 1e-6, "bcast_add_t")
+
+
+@pytest.mark.parametrize("p16", [None, torch.bfloat16, torch.float16])
+def test_adamw_and_sumsq(p16):
+    n = 1000
+    p, g = rnd(n, seed=25), rnd(n, seed=26)
+    m, v = rnd(n, seed=27).abs() * 0.1, rnd(n, seed=28).abs() * 0.01
+    want = [t.clone() for t in (p, m, v)]
+    C.adamw(want[0], g, want[1], want[2], lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.1, step=3, grad_scale=0.5)
+    h = torch.zeros(n, dtype=p16) if p16 is not None else None
+    with _hipemu.emulated() as hip:
+        hip.adamw(p, g, m, v, lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.1, step=3, grad_scale=0.5, p16=h)
+        sq = hip.sumsq(g)
+    for got, w, nme in zip((p, m, v), want, "pmv"):
+        close(got, w, 2e-6, nme)
+    if h is not None:
+        assert torch.equal(h, p.to(p16))
+    assert abs(sq.item() - g.pow(2).sum().item()) <= 1e-4 * g.pow(2).sum().item()
+
+
+def test_llama_backward_on_emulated_kernels():
+    """llama_forward_taped + CE + llama_backward on a small Llama (2 layers, 2 heads x 128, vocab 256, right-padded batch) with every
+    training entry point on the emulated kernels (forward entry points stay on the contract backend): real strides, alignments and
+    workspaces go through the C entry points' argument checks; result == the same graph on the contract backend."""
+    from stllm_amd import hip, runtime, synth, training
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    train_names = ["transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu", "swiglu_bwd", "rope_bwd", "attention_bwd",
+                   "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum", "relu_bwd", "bcast_add_t", "adamw", "sumsq"]
+    real = {n: getattr(hip, n) for n in train_names}
+    model = STLLMForCausalLM(StllmConfig(hidden_size=256, intermediate_size=384, num_hidden_layers=2, num_attention_heads=2,
+                                         vocab_size=256), device="cpu")
+    synth.fill_module_(model, 0, "")
+    B, S = 2, 40
+    emb = rnd(B, S, 256, seed=30, scale=0.5)
+    att = torch.ones(B, S, dtype=torch.long)
+    att[1, 29:] = 0
+    labels = torch.randint(0, 256, (B * S,), generator=torch.Generator().manual_seed(31)).to(torch.int32)
+    labels[::3] = -100
+
+    def run():
+        h32, h16, tape = training.llama_forward_taped(model.model, emb, att)
+        W = model.lm_weight(torch.float32)
+        logits = hip.gemm(h16, W, dtype=torch.float32, out_f32=True)
+        dlog = hip.cross_entropy_bwd(logits, labels, 1.0 / 50, dtype=torch.float32, vocab=256)
+        d_h16, dw = training.linear_bwd(dlog, h16, W, torch.float32)
+        d_emb, grads = training.llama_backward(model.model, tape, d_h16, rnd(B * S, 256, seed=32, scale=0.01))
+        grads["lm_head.weight"], grads["d_emb"] = dw, d_emb
+        return grads
+
+    with C.installed(), runtime.use_dtype("fp32"):
+        want = run()
+        with _hipemu.emulated():
+            for n, f in real.items():
+                setattr(hip, n, f)
+            got = run()
+    assert set(got) == set(want)
+    for n in want:
+        close(got[n], want[n], 2e-5, n)
