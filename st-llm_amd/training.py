@@ -369,6 +369,22 @@ class AdamW:
         return norm
 
 
+def cosine_lr(step, total_steps, base_lr, warmup_ratio=0.03):
+    """HF `get_cosine_schedule_with_warmup` as configured by config/*_stllm_qa.yaml (`lr_scheduler_type: cosine`,
+    `warmup_ratio: 0.03`; Trainer uses ceil(total * ratio) warm-up steps): the learning rate of optimizer step `step` (0-based)."""
+    import math
+    warm = math.ceil(total_steps * warmup_ratio)
+    if step < warm:
+        return base_lr * step / max(1, warm)
+    progress = (step - warm) / max(1, total_steps - warm)
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+
+
+def trainable_state_dict(model):
+    """what train_hf.py:188-203 writes at a checkpoint: the parameters that require grad in the reference, by its names"""
+    return {n: p.detach().clone() for n, p in trainable_parameters(model)}
+
+
 def train_step(model, samples, optimizer):
     """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1)."""
     loss, loss_mvm, grads = loss_and_grads(model, samples)

@@ -93,3 +93,17 @@ def test_zero1_sharded_step_matches_single_process():
             assert abs(a - b) <= 1e-5 * b
         for got, (n, want) in zip(params, named):
             assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (rank, n, (got - want).abs().max())
+
+
+def test_cosine_schedule_matches_hf():
+    import math
+    from transformers import get_cosine_schedule_with_warmup
+    from stllm_amd import training
+    total, base = 137, 2e-5
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=base)
+    sch = get_cosine_schedule_with_warmup(opt, math.ceil(total * 0.03), total)
+    for step in range(total):
+        assert abs(sch.get_last_lr()[0] - training.cosine_lr(step, total, base)) <= 1e-12, step
+        opt.step()
+        sch.step()
