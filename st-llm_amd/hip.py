@@ -50,6 +50,45 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hi
 _lib = None
 
 
+def _bind(L, strict=True):
+    """argument / result types of the forward entry points on a loaded library.  strict=False skips symbols the library does not
+    export (the host-emulated test build of a subset of the sources, tests/hipemu)."""
+    def B(name, argtypes=None, restype=c_int):
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            if strict:
+                raise
+            return
+        if argtypes is not None:
+            fn.argtypes = argtypes
+        fn.restype = restype
+    B("stllm_last_error", None, c_char_p)
+    B("stllm_abi_version")
+    B("stllm_last_kernel", None, c_char_p)
+    B("stllm_gemm", [ctypes.POINTER(GemmArgs), c_void_p])
+    B("stllm_layernorm", [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p])
+    B("stllm_rmsnorm", [c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p])
+    B("stllm_attention", [c_int] + [c_void_p, c_int64, c_int64] * 4 + [c_int] * 5 + [c_float, c_int, c_void_p, c_void_p])
+    B("stllm_gather_rows", [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                            c_float, c_void_p])
+    B("stllm_mean_t", [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p])
+    B("stllm_vit_cls_rows", [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p])
+    B("stllm_cosine_rows", [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p])
+    B("stllm_cross_entropy_rows", [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p])
+    B("stllm_cast_rows", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p])
+    B("stllm_gemm_workspace_bytes", None, c_int64)
+    B("stllm_set_option", [c_char_p, c_int])
+    B("stllm_gemm_workspace_status", [c_void_p, c_void_p])
+    B("stllm_preprocess_workspace_bytes", [c_int, c_int, c_int], c_int64)
+    B("stllm_preprocess_frames", [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p])
+    B("stllm_attention_decode_workspace_bytes", [c_int, c_int, c_int], c_int64)
+    B("stllm_attention_decode", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
+                                 c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p])
+    B("stllm_gemm_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
+    return L
+
+
 def lib():
     """Load libstllm_hip.so (built in-tree by stllm_amd.build / __graft_entry__.build())."""
     global _lib
@@ -57,39 +96,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found — run `python __graft_entry__.py` (build()) first; "
                                "there is no CPU/eager fallback for the HIP path")
-        L = ctypes.CDLL(LIB_PATH)
-        L.stllm_last_error.restype = c_char_p
-        L.stllm_abi_version.restype = c_int
-        L.stllm_last_kernel.restype = c_char_p
-        L.stllm_gemm.argtypes = [ctypes.POINTER(GemmArgs), c_void_p]
-        L.stllm_layernorm.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64,
-                                      c_void_p, c_int64, c_int, c_int, c_void_p]
-        L.stllm_rmsnorm.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p,
-                                    c_int64, c_int, c_int, c_void_p]
-        L.stllm_attention.argtypes = [c_int] + [c_void_p, c_int64, c_int64] * 4 + [c_int] * 5 + [c_float, c_int,
-                                                                                              c_void_p, c_void_p]
-        L.stllm_gather_rows.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
-                                        c_void_p, c_int64, c_int, c_int, c_float, c_void_p]
-        L.stllm_mean_t.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]
-        L.stllm_vit_cls_rows.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]
-        L.stllm_cosine_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
-                                        c_int, c_void_p]
-        L.stllm_cross_entropy_rows.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]
-        L.stllm_cast_rows.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p]
-        for n in EXPORTS[3:]:
-            getattr(L, n).restype = c_int
-        L.stllm_gemm_workspace_bytes.restype = c_int64
-        L.stllm_set_option.argtypes = [c_char_p, c_int]
-        L.stllm_gemm_workspace_status.argtypes = [c_void_p, c_void_p]
-        L.stllm_preprocess_workspace_bytes.restype = c_int64
-        L.stllm_preprocess_workspace_bytes.argtypes = [c_int, c_int, c_int]
-        L.stllm_preprocess_frames.argtypes = [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]
-        L.stllm_attention_decode_workspace_bytes.restype = c_int64
-        L.stllm_attention_decode_workspace_bytes.argtypes = [c_int, c_int, c_int]
-        L.stllm_attention_decode.argtypes = [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
-                                             c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]
-        L.stllm_gemm_plan.argtypes = [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]
-        _lib = L
+        _lib = _bind(ctypes.CDLL(LIB_PATH))
     return _lib
 
 

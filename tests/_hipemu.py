@@ -63,8 +63,7 @@ def emulated():
     if ON_DEVICE:
         yield _DeviceProxy(hip)
         return
-    L = ctypes.CDLL(_builder().build())
-    L.stllm_last_error.restype = ctypes.c_char_p
+    L = hip._bind(ctypes.CDLL(_builder().build()), strict=False)
     saved = (hip._lib, hip._train_bound, hip._stream, hip._req)
     hip._lib, hip._train_bound = L, False
     hip._stream = lambda: None

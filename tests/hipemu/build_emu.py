@@ -8,9 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip"]
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-DYN = "#include <hip/hip_runtime.h>\nnamespace { alignas(16) float smem[32768]; }\n"
+DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; }}\n"   # 160 KB of dynamic LDS
 
 
 def build(force=False):
@@ -22,11 +22,15 @@ def build(force=False):
     tus = []
     for f in KERNEL_SOURCES:
         text = open(os.path.join(CSRC, f)).read()
-        dyn = "extern __shared__" in text
+        m = re.search(r"extern\s+__shared__[^;]*?(\w+)\s+smem\[\]", text)
+        head = ""
+        if m:
+            ty = m.group(1)
+            head = DYN.format(type=ty, n=163840 // (4 if ty == "float" else 1))
         text = re.sub(r"extern\s+__shared__", "EMU_DYN_SHARED", text)
         tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
         with open(tu, "w") as fh:
-            fh.write((DYN if dyn else "") + text)
+            fh.write(head + text)
         tus.append(tu)
     cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
            "-I", HERE, "-I", CSRC] + tus + [os.path.join(CSRC, "error.cpp"), "-o", lib]

@@ -42,18 +42,21 @@ inline float __logf(float x) { return logf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) (c)
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) (c)
-#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) (c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32_f32(a, b, c)
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_med3(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, n, o, a) ((void)0)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()   /* lanes are independent threads here: make it a real barrier */
 
 // ---- block / wave state ---------------------------------------------------------------------------------------------
 struct emu_block {
   std::barrier<> all;
   std::vector<std::unique_ptr<std::barrier<>>> wave;
   std::vector<float> xch;
-  explicit emu_block(int n) : all(n), xch(n) {
+  std::vector<float> ma, mb;            // MFMA operand exchange: [thread][8]
+  explicit emu_block(int n) : all(n), xch(n), ma(8 * n), mb(8 * n) {
     for (int w = 0; w < (n + 63) / 64; ++w) wave.emplace_back(new std::barrier<>(std::min(64, n - 64 * w)));
   }
 };
@@ -69,6 +72,53 @@ inline float __shfl_xor(float v, int mask, int width = 64) {
   bar.arrive_and_wait();
   return r;
 }
+inline int __any(int pred) {                                  // wave vote
+  const int t = threadIdx.x, w0 = t & ~63;
+  auto& bar = *emu_cur->wave[t >> 6];
+  emu_cur->xch[t] = pred ? 1.0f : 0.0f;
+  bar.arrive_and_wait();
+  int r = 0;
+  for (int l = 0; l < 64 && w0 + l < (int)emu_cur->xch.size(); ++l) r |= emu_cur->xch[w0 + l] != 0.0f;
+  bar.arrive_and_wait();
+  return r;
+}
+inline void emu_wave_barrier() { emu_cur->wave[threadIdx.x >> 6]->arrive_and_wait(); }
+
+// v_mfma_f32_32x32x{8,16}_{f16,bf16}: D[32x32] += A[32xK] B[Kx32], K = 2*KPL; lane l holds A[l%32][KPL*(l/32) .. +KPL) and
+// B[KPL*(l/32) .. +KPL)[l%32]; D register j of lane l is D[8*(j/4) + 4*(l/32) + j%4][l%32]  (CDNA3/4 ISA guide, 32x32 layouts).
+template <int KPL, typename VA, typename VC> inline VC emu_mfma_32x32(VA a, VA b, VC c) {
+  const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
+  auto& bar = *emu_cur->wave[t >> 6];
+  for (int e = 0; e < KPL; ++e) { emu_cur->ma[8 * t + e] = (float)a[e]; emu_cur->mb[8 * t + e] = (float)b[e]; }
+  bar.arrive_and_wait();
+  const int n = lane & 31;
+  for (int j = 0; j < 16; ++j) {
+    const int m = 8 * (j / 4) + 4 * (lane / 32) + (j % 4);
+    float acc = c[j];
+    for (int k = 0; k < 2 * KPL; ++k)
+      acc += emu_cur->ma[8 * (w0 + m + 32 * (k / KPL)) + k % KPL] * emu_cur->mb[8 * (w0 + n + 32 * (k / KPL)) + k % KPL];
+    c[j] = acc;
+  }
+  bar.arrive_and_wait();
+  return c;
+}
+template <typename VC> inline VC emu_mfma_32x32_f32(float a, float b, VC c) {   // 32x32x2: lane l holds A[l%32][l/32], B[l/32][l%32]
+  const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
+  auto& bar = *emu_cur->wave[t >> 6];
+  emu_cur->ma[8 * t] = a;
+  emu_cur->mb[8 * t] = b;
+  bar.arrive_and_wait();
+  const int n = lane & 31;
+  for (int j = 0; j < 16; ++j) {
+    const int m = 8 * (j / 4) + 4 * (lane / 32) + (j % 4);
+    float acc = c[j];
+    for (int k = 0; k < 2; ++k) acc += emu_cur->ma[8 * (w0 + m + 32 * k)] * emu_cur->mb[8 * (w0 + n + 32 * k)];
+    c[j] = acc;
+  }
+  bar.arrive_and_wait();
+  return c;
+}
+
 inline float atomicAdd(float* addr, float v) {
   std::atomic_ref<float> a(*addr);
   float old = a.load();

@@ -231,3 +231,23 @@ def test_llama_backward_on_emulated_kernels():
     assert set(got) == set(want)
     for n in want:
         close(got[n], want[n], 2e-5, n)
+
+
+# ---- cross-check of the emulator itself: the FORWARD attention kernels are parity-green on the MI355X (tests/test_kernels_gpu.py),
+# so the emulated run of the same sources must reproduce the contract too — this pins the shim's MFMA / shuffle / vote / barrier
+# semantics (operand and accumulator lane layouts of v_mfma_f32_32x32x16) to what the hardware does. ----------------------------
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="emulator self-check")
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [dict(B=1, H=2, S=70, D=88, causal=False, lens=None),          # ViT-like (head_dim 88 padded to 96)
+                                   dict(B=2, H=1, S=45, D=64, causal=False, lens=[45, 20]),       # Q-Former-like, key mask
+                                   dict(B=2, H=2, S=70, D=128, causal=True, lens=[70, 33])])      # Llama prefill, right padding
+def test_emulated_forward_attention_matches_contract(dtype, shape):
+    B, H, S, D = shape["B"], shape["H"], shape["S"], shape["D"]
+    HD = H * D
+    qkv = rnd(B * S, 3 * HD, seed=40, dtype=dtype, scale=0.8)
+    kv_len = None if shape["lens"] is None else torch.tensor(shape["lens"], dtype=torch.int32)
+    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+    want = C.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5, causal=shape["causal"], kv_len=kv_len)
+    with _hipemu.emulated() as hip:
+        got = hip.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5, causal=shape["causal"], kv_len=kv_len)
+    close(got, want, 4 * TOL[dtype] if dtype != torch.float32 else 2e-5, "attention forward (emulated)")
