@@ -8,9 +8,21 @@
 //             dQ = scale * dS K
 //   3. dkv  : one workgroup per 32 keys, sweeps the query tiles that see them: dV = P^T dO,  dK = scale * dS^T Q
 // Tiles are staged in LDS as fp32 (row stride 132 floats: the float4 reads of 8 consecutive rows hit 32 distinct banks).
-// FIRST VERSION: the 32x32x128 tile products run on the VALU (fp32 FMA) — correct for bf16 / f16 / f32 operands alike and
-// simple enough to validate; the MFMA version (same tiling, 32x32x16 MFMA on 16-bit tiles) replaces the inner products once
-// this one is parity-green on the device.  Algorithmic FLOPs: 5 * 2 * S^2/2 * 128 per (b, h) for causal masks.
+// Two implementations of the same structure:
+//   * VALU (fp32 FMA on fp32 LDS tiles, row stride 132 floats): exact-fp32 "verify" mode, and the reference the MFMA path is
+//     compared with (STLLM_ATTN_BWD_VALU=1 forces it for 16-bit operands too);
+//   * MFMA (bf16 / f16, v_mfma_f32_32x32x16, "everything transposed" like the forward kernel in attention.hip): a wave owns 32
+//     queries (dQ kernel) or 32 keys (dK/dV kernel) as the COLUMNS of every accumulator tile, so the per-row softmax statistics
+//     are per-lane scalars (dQ) and the P / dS accumulators are already in B-operand form for the second product:
+//        dQ kernel :  S^T = K Q^T,  dP^T = V dO^T           (A = K / V rows from LDS, B = Q / dO fragments in VGPRs)
+//                     dQ^T += K^T dS^T                      (A = K^T from LDS, B = dS^T accumulator registers, packed to 16 bit)
+//        dKV kernel:  S = Q K^T,   dP = dO V^T              (A = Q / dO rows from LDS, B = K / V fragments in VGPRs)
+//                     dV^T += dO^T P,  dK^T += Q^T dS       (A = dO^T / Q^T from LDS, B = P / dS accumulator registers)
+//     The statistics pass (log-sum-exp in the log2 domain + dO.o) is the first sweep of the dQ kernel, written to the workspace
+//     for the dK/dV kernel.  24 MFMAs per (32 queries x 32 keys) in the dQ sweep + 8 in its statistics sweep, 32 in the dK/dV sweep.
+// Algorithmic FLOPs: 5 * 2 * S^2/2 * 128 per (b, h) for causal masks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -271,6 +283,243 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(Ptr q, Ptr k, Ptr v, 
   }
 }
 
+
+// =========================================================================================================================
+// MFMA path (16-bit operands)
+// =========================================================================================================================
+constexpr int kNW = 4;                  // waves per workgroup: 128 queries (dQ) / 128 keys (dK/dV)
+constexpr int kKS = kD / 16;            // k-steps of a 128-deep contraction
+constexpr int kDB = kD / 32;            // 32-row blocks of a [128 x 32] transposed accumulator
+constexpr int kRowPitch = kD * 2 + 16;  // bytes per row-major tile row in LDS (conflict-free ds_read_b128)
+constexpr int kTPitch = 32 * 2 + 8;     // bytes per row of a transposed tile [d][32 rows]
+constexpr float kNegBig = -1.0e30f;
+
+// stage rows [row0, row0 + 32) of head (b, h): row-major copy (rows_lds) and, if t_lds, the transposed copy [d][row]
+template <typename T>
+__device__ __forceinline__ void stage_tile16(char* rows_lds, char* t_lds, const Ptr& t, int b, int h, int row0, int S, int tid) {
+  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)h * kD) * 2;
+#pragma unroll
+  for (int c = 0; c < (32 * (kD / 8)) / (64 * kNW); ++c) {
+    const int ch = tid + c * 64 * kNW;
+    const int cc = ch >> 5, row = ch & 31;      // consecutive lanes = consecutive rows: conflict-free transposed writes
+    i32x4 x = {0, 0, 0, 0};
+    if (row0 + row < S) x = *reinterpret_cast<const i32x4*>(base + ((int64_t)(row0 + row) * t.rs + cc * 8) * 2);
+    *reinterpret_cast<i32x4*>(rows_lds + row * kRowPitch + cc * 16) = x;
+    if (t_lds) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t w = (uint32_t)x[e];
+        *reinterpret_cast<uint16_t*>(t_lds + (cc * 8 + 2 * e) * kTPitch + row * 2) = (uint16_t)(w & 0xffff);
+        *reinterpret_cast<uint16_t*>(t_lds + (cc * 8 + 2 * e + 1) * kTPitch + row * 2) = (uint16_t)(w >> 16);
+      }
+    }
+  }
+}
+// this lane's B-operand fragments of row `row`: X[row][ks*16 + lh*8 .. +8], zero beyond S
+template <typename T>
+__device__ __forceinline__ void load_frags(i32x4* f, const Ptr& t, int b, int h, int row, int S, int lh) {
+  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)(row < S ? row : 0) * t.rs + (int64_t)h * kD) * 2;
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) {
+    const i32x4 z = {0, 0, 0, 0};
+    f[ks] = row < S ? *reinterpret_cast<const i32x4*>(base + (ks * 16 + lh * 8) * 2) : z;
+  }
+}
+template <typename T> __device__ __forceinline__ float dot8(i32x4 a, i32x4 b) {
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t ua = (uint32_t)a[e], ub = (uint32_t)b[e];
+    s = fmaf(Elem<T>::unpack((uint16_t)(ua & 0xffffu)), Elem<T>::unpack((uint16_t)(ub & 0xffffu)), s);
+    s = fmaf(Elem<T>::unpack((uint16_t)(ua >> 16)), Elem<T>::unpack((uint16_t)(ub >> 16)), s);
+  }
+  return s;
+}
+// X . Y^T for one 32x32 tile over the 128-deep contraction: A rows from a row-major LDS tile, B fragments in registers
+template <typename T> __device__ __forceinline__ f32x16 tile_nt(const char* rows_lds, const i32x4* bf, int li, int lh) {
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) {
+    const i32x4 af = *reinterpret_cast<const i32x4*>(rows_lds + li * kRowPitch + (ks * 2 + lh) * 16);
+    s = Elem<T>::mfma(af, bf[ks], s);
+  }
+  return s;
+}
+// acc^T[d][col] += X^T[d][row] . W[row][col]: A from the transposed LDS tile, B = the 32x32 accumulator `w` (rows x this lane's
+// column) packed to 16 bit; the accumulator register order IS the contraction order (see attention.hip)
+template <typename T> __device__ __forceinline__ void tile_tn(f32x16* acc, const char* t_lds, const f32x16& w, int li, int lh) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    i32x4 bf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bf[e] = (int)(Elem<T>::pack2(w[a * 8 + 2 * e], w[a * 8 + 2 * e + 1]));
+#pragma unroll
+    for (int i = 0; i < kDB; ++i) {
+      const char* tp = t_lds + (i * 32 + li) * kTPitch + (16 * a + 4 * lh) * 2;
+      const i32x2 lo = *reinterpret_cast<const i32x2*>(tp);
+      const i32x2 hi = *reinterpret_cast<const i32x2*>(tp + 16);
+      const i32x4 af = {lo[0], lo[1], hi[0], hi[1]};
+      acc[i] = Elem<T>::mfma(af, bf, acc[i]);
+    }
+  }
+}
+// lane holds acc^T[d = i*32 + 8g + 4lh + (0..3)][row]: 8-byte stores of 4 consecutive d
+template <typename T> __device__ __forceinline__ void store_acc_t(const f32x16* acc, const MPtr& t, int b, int h, int row, int lh, float mul) {
+  uint16_t* op = reinterpret_cast<uint16_t*>(t.p) + (int64_t)b * t.bs + (int64_t)row * t.rs + (int64_t)h * kD;
+#pragma unroll
+  for (int i = 0; i < kDB; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 pk;
+      pk.x = Elem<T>::pack2(acc[i][4 * g + 0] * mul, acc[i][4 * g + 1] * mul);
+      pk.y = Elem<T>::pack2(acc[i][4 * g + 2] * mul, acc[i][4 * g + 3] * mul);
+      *reinterpret_cast<uint2*>(op + i * 32 + 8 * g + 4 * lh) = pk;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, float* __restrict__ ws, int H,
+                                                                   int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
+  __shared__ __attribute__((aligned(16))) char k_lds[32 * kRowPitch];
+  __shared__ __attribute__((aligned(16))) char v_lds[32 * kRowPitch];
+  __shared__ __attribute__((aligned(16))) char kt_lds[kD * kTPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_blk0 = blockIdx.x * (32 * kNW);
+  const int qrow = q_blk0 + wave * 32 + li;                 // this lane's query (column of every accumulator tile)
+  const int wave_q_last = q_blk0 + wave * 32 + 31;
+  const int kvlen = kv_len ? min(kv_len[b], S) : S;
+  const int kv_end = causal ? min(kvlen, q_blk0 + 32 * kNW) : kvlen;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  i32x4 qf[kKS], dof[kKS];
+  load_frags<T>(qf, q, b, h, qrow, S, lh);
+  load_frags<T>(dof, dO, b, h, qrow, S, lh);
+  float delta = 0.0f;
+  {
+    i32x4 of[kKS];
+    load_frags<T>(of, o, b, h, qrow, S, lh);
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) delta += dot8<T>(dof[ks], of[ks]);
+    delta += __shfl_xor(delta, 32, 64);
+  }
+  // ---- sweep 1: log-sum-exp of the scaled scores, log2 domain ------------------------------------------------------------
+  float m_run = kNegBig, l_run = 0.0f;
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
+    __syncthreads();
+    stage_tile16<T>(k_lds, nullptr, k, b, h, kv0, S, tid);
+    __syncthreads();
+    if (causal && kv0 > wave_q_last) continue;
+    f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
+    float mx = kNegBig;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool dead = (kv >= kvlen) || (causal && kv > qrow);
+      s[r] = dead ? kNegBig : s[r];
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs += s[r] > -1.0e29f ? __builtin_amdgcn_exp2f((s[r] - m_new) * scale_log2) : 0.0f;
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2) + rs;
+    m_run = m_new;
+  }
+  const float lse2 = m_run * scale_log2 + __log2f(l_run);
+  if (lh == 0 && qrow < S) {
+    float* w = ws + ((int64_t)(b * H + h) * S + qrow) * 2;
+    w[0] = lse2;
+    w[1] = delta;
+  }
+  // ---- sweep 2: dQ^T += K^T dS^T ---------------------------------------------------------------------------------------------
+  f32x16 acc[kDB];
+#pragma unroll
+  for (int i = 0; i < kDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
+    __syncthreads();
+    stage_tile16<T>(k_lds, kt_lds, k, b, h, kv0, S, tid);
+    stage_tile16<T>(v_lds, nullptr, v, b, h, kv0, S, tid);
+    __syncthreads();
+    if (causal && kv0 > wave_q_last) continue;
+    f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
+    const f32x16 dp = tile_nt<T>(v_lds, dof, li, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const bool dead = (kv >= kvlen) || (causal && kv > qrow) || qrow >= S;
+      const float pr = dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, -lse2));
+      s[r] = pr * (dp[r] - delta);
+    }
+    tile_tn<T>(acc, kt_lds, s, li, lh);
+  }
+  if (qrow < S) store_acc_t<T>(acc, dq, b, h, qrow, lh, scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws,
+                                                                    int H, int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
+  __shared__ __attribute__((aligned(16))) char q_lds[32 * kRowPitch];
+  __shared__ __attribute__((aligned(16))) char do_lds[32 * kRowPitch];
+  __shared__ __attribute__((aligned(16))) char qt_lds[kD * kTPitch];
+  __shared__ __attribute__((aligned(16))) char dot_lds[kD * kTPitch];
+  __shared__ float st_lds[64];                               // (lse2, delta) of the 32 queries of the tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int k_blk0 = blockIdx.x * (32 * kNW);
+  const int krow = k_blk0 + wave * 32 + li;                  // this lane's key (column of every accumulator tile)
+  const int wave_k_first = k_blk0 + wave * 32;
+  const int kvlen = kv_len ? min(kv_len[b], S) : S;
+  const float scale_log2 = scale * 1.4426950408889634f;
+  i32x4 kf[kKS], vf[kKS];
+  load_frags<T>(kf, k, b, h, krow, S, lh);
+  load_frags<T>(vf, v, b, h, krow, S, lh);
+  f32x16 accv[kDB], acck[kDB];
+#pragma unroll
+  for (int i = 0; i < kDB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accv[i][r] = acck[i][r] = 0.0f;
+  const float* wrow = ws + (int64_t)(b * H + h) * S * 2;
+  for (int q0 = causal ? k_blk0 : 0; q0 < S; q0 += 32) {
+    __syncthreads();
+    stage_tile16<T>(q_lds, qt_lds, q, b, h, q0, S, tid);
+    stage_tile16<T>(do_lds, dot_lds, dO, b, h, q0, S, tid);
+    if (tid < 64) st_lds[tid] = (q0 + (tid >> 1) < S) ? wrow[2 * (q0 + (tid >> 1)) + (tid & 1)] : 0.0f;
+    __syncthreads();
+    if (causal && q0 + 31 < wave_k_first) continue;          // every query of the tile precedes every key of this wave
+    f32x16 s = tile_nt<T>(q_lds, kf, li, lh);                // s[r] = S[query (r&3)+8(r>>2)+4lh][key krow]
+    f32x16 ds = tile_nt<T>(do_lds, vf, li, lh);              // dP, same layout
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * lh, qq = q0 + ql;
+      const bool dead = qq >= S || krow >= kvlen || (causal && krow > qq);
+      const float pr = dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, -st_lds[2 * ql]));
+      ds[r] = pr * (ds[r] - st_lds[2 * ql + 1]);
+      s[r] = pr;
+    }
+    tile_tn<T>(accv, dot_lds, s, li, lh);                    // dV^T += dO^T P
+    tile_tn<T>(acck, qt_lds, ds, li, lh);                    // dK^T += Q^T dS
+  }
+  if (krow < S) {
+    store_acc_t<T>(accv, dv, b, h, krow, lh, 1.0f);
+    store_acc_t<T>(acck, dk, b, h, krow, lh, scale);
+  }
+}
+
+template <typename T>
+int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, float scale, int causal,
+                    const int32_t* kv_len, hipStream_t st) {
+  const dim3 grid((S + 32 * kNW - 1) / (32 * kNW), H, B), block(64 * kNW);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<T>, grid, block, 0, st, q, k, v, o, dO, dq, ws, H, S, scale, causal, kv_len);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<T>, grid, block, 0, st, q, k, v, dO, dk, dv, ws, H, S, scale, causal, kv_len);
+  return STLLM_OK;
+}
+
 constexpr int kLdsStats = 2 * kTile * 4;
 constexpr int kLdsDq = (4 * kTile + kT * 33) * 4;
 constexpr int kLdsDkv = (4 * kTile + 2 * kT * 33) * 4;
@@ -317,9 +566,13 @@ extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* ws = reinterpret_cast<float*>(workspace);
   int rc;
+  const char* force = getenv("STLLM_ATTN_BWD_VALU");
+  const bool valu = force && force[0] == '1';
   switch (dtype) {
-    case STLLM_BF16: rc = launch_bwd<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
-    case STLLM_F16: rc = launch_bwd<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    case STLLM_BF16: rc = valu ? launch_bwd<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s)
+                               : launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    case STLLM_F16: rc = valu ? launch_bwd<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s)
+                              : launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
     case STLLM_F32: rc = launch_bwd<float>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
     default: stllm_set_error("stllm_attention_bwd: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;
   }

@@ -39,6 +39,7 @@ using std::max;
 using std::min;
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
+inline float __log2f(float x) { return log2f(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
