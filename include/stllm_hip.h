@@ -113,7 +113,8 @@ int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_gemv"  = -1 on | 0 off: the skinny M <= 4 kernel of the decode regime (st-llm_amd/csrc/gemv.hip)
+ *   "gemm_gemv"  = -1 on | 0 off | 2 up to M = 8: the skinny M <= 4 kernel of the decode regime (st-llm_amd/csrc/gemv.hip); 2 extends
+ *                  it to the 5 beams of demo.py's beam search (staged: checked in emulation, not yet timed on the device)
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
 int stllm_set_option(const char* key, int value);

@@ -888,11 +888,11 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
-    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): 0 = keep M <= 4 on the tile kernels
+    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): 0 = keep M <= 4 on the tile kernels, 2 = GEMV up to M = 8
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
     const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4;   // tests / experiments
-    if (p.M <= 4 && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
+    if (p.M <= (gemv_mode == 2 ? 8 : 4) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
     }

@@ -1,4 +1,5 @@
-// Skinny GEMM for the decode regime:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T) with M <= 4, bf16 / fp16.
+// Skinny GEMM for the decode regime:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T) with M <= 4 (M <= 8 with
+// stllm_set_option("gemm_gemv", 2): the 5 beams of demo.py's beam search; staged, off by default until timed), bf16 / fp16.
 //
 // One token per sequence means every weight matrix is streamed from HBM once per step and used for M <= 4 rows: the
 // problem is HBM-bound (Vicuna-7B: 13.2 GB per token), the matrix cores are useless (a 64-row MFMA tile would be 98 % padding).
@@ -164,7 +165,9 @@ int launch_gemv_m(const GemmParams& p, hipStream_t stream) {
   switch (p.M) {
     case 1: return launch_gemv<T, EPI, ACT, OF32, 1>(p, stream);
     case 2: return launch_gemv<T, EPI, ACT, OF32, 2>(p, stream);
-    default: return launch_gemv<T, EPI, ACT, OF32, 4>(p, stream);   // M = 3, 4
+    case 3: case 4: return launch_gemv<T, EPI, ACT, OF32, 4>(p, stream);
+    case 5: case 6: return launch_gemv<T, EPI, ACT, OF32, 6>(p, stream);
+    default: return launch_gemv<T, EPI, ACT, OF32, 8>(p, stream);   // M = 7, 8
   }
 }
 
@@ -184,9 +187,12 @@ int dispatch_gemv(int epilogue, const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-// M <= 4, 16-bit dtypes, K*2*M bytes of A must fit the LDS; returns STLLM_ERR_UNSUPPORTED otherwise (caller falls back)
+// M <= 8 (the caller decides how far it goes), 16-bit dtypes, the staged rows of A (1, 2, 4, 6 or 8 x K x 2 bytes) must fit the LDS;
+// returns STLLM_ERR_UNSUPPORTED otherwise (caller falls back to the tile kernels)
 int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream) {
-  if (p.M < 1 || p.M > 4 || p.N % 64 || p.K % 8 || (int64_t)(p.M > 2 ? 4 : p.M) * p.K * 2 > 150 * 1024) return STLLM_ERR_UNSUPPORTED;
+  if (p.M < 1 || p.M > 8) return STLLM_ERR_UNSUPPORTED;
+  const int mr = p.M <= 2 ? p.M : (p.M + 1) / 2 * 2;
+  if (p.N % 64 || p.K % 8 || (int64_t)mr * p.K * 2 > 150 * 1024) return STLLM_ERR_UNSUPPORTED;
   if ((p.lda_b % 16) || (p.ldw_b % 16)) return STLLM_ERR_UNSUPPORTED;
   if (dtype == STLLM_BF16) return dispatch_gemv<bf16_t>(epilogue, p, stream);
   if (dtype == STLLM_F16) return dispatch_gemv<f16_t>(epilogue, p, stream);

@@ -41,6 +41,8 @@ class _DeviceProxy:
                     y = x.cuda()
                     moved.append((x, y))
                     return y
+                if isinstance(x, (tuple, list)):
+                    return type(x)(mv(e) for e in x)
                 return x
 
             def back(r):
@@ -64,11 +66,13 @@ def emulated():
         yield _DeviceProxy(hip)
         return
     L = hip._bind(ctypes.CDLL(_builder().build()), strict=False)
-    saved = (hip._lib, hip._train_bound, hip._stream, hip._req)
+    import torch
+    saved = (hip._lib, hip._train_bound, hip._stream, hip._req, hip.gemm_workspace)
     hip._lib, hip._train_bound = L, False
     hip._stream = lambda: None
     hip._req = lambda t, dtype=None, what="tensor": t
+    hip.gemm_workspace = lambda device: torch.zeros(16, dtype=torch.uint8)
     try:
         yield hip
     finally:
-        hip._lib, hip._train_bound, hip._stream, hip._req = saved
+        hip._lib, hip._train_bound, hip._stream, hip._req, hip.gemm_workspace = saved

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip"]
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; }}\n"   # 160 KB of dynamic LDS
 
@@ -16,7 +16,7 @@ DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libstllm_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h")]
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "gemv_entry.cpp")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
     tus = []
@@ -33,7 +33,7 @@ def build(force=False):
             fh.write(head + text)
         tus.append(tu)
     cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
-           "-I", HERE, "-I", CSRC] + tus + [os.path.join(CSRC, "error.cpp"), "-o", lib]
+           "-I", HERE, "-I", CSRC] + tus + [os.path.join(HERE, "gemv_entry.cpp"), os.path.join(CSRC, "error.cpp"), "-o", lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulation build failed:\n" + r.stderr[-4000:])

@@ -107,3 +107,29 @@ def test_cosine_schedule_matches_hf():
         assert abs(sch.get_last_lr()[0] - training.cosine_lr(step, total, base)) <= 1e-12, step
         opt.step()
         sch.step()
+
+
+def test_optimizer_resume_is_exact():
+    """checkpoint after 2 steps (trainable masters + optimizer shard), rebuild, resume: steps 3-4 are bit-identical"""
+    from stllm_amd import training
+    with _cpu_backend.installed():
+        named = _params()
+        opt = training.AdamW(named, lr=3e-3, weight_decay=0.01, max_grad_norm=0.5)
+        for step in range(2):
+            opt.step(_grads(named, step))
+        ckpt_p = [p.detach().clone() for _, p in named]
+        ckpt_o = opt.state_dict()
+        for step in range(2, 4):
+            opt.step(_grads(named, step))
+        want = [p.detach().clone() for _, p in named]
+        named2 = _params(seed=99)
+        for (_, p), c in zip(named2, ckpt_p):
+            p.data.copy_(c)
+        opt2 = training.AdamW(named2, lr=3e-3, weight_decay=0.01, max_grad_norm=0.5)
+        opt2.load_state_dict(ckpt_o)
+        for step in range(2, 4):
+            opt2.step(_grads(named2, step))
+    for (n, p), w in zip(named2, want):
+        assert torch.equal(p, w), n
+    with pytest.raises(ValueError):
+        training.AdamW(_params()[:2], lr=1e-3).load_state_dict(ckpt_o)

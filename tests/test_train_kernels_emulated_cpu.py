@@ -38,10 +38,9 @@ def test_transpose_zero_pads(dtype):
     assert got.shape == (130, 128) and torch.equal(got, C.transpose(x, pad=64))
 
 
-@pytest.mark.parametrize("dy_dtype", DTYPES)
-@pytest.mark.parametrize("accumulate", [True, False])
+@pytest.mark.parametrize("dy_dtype,accumulate", [(torch.float32, True), (torch.bfloat16, True), (torch.float16, False)])
 def test_rmsnorm_bwd(dy_dtype, accumulate):
-    M, D = 37, 264
+    M, D = 37, 136
     x, gamma, dy = rnd(M, D, seed=1), rnd(D, seed=2) + 1.0, rnd(M, D, seed=3, dtype=dy_dtype)
     dx0 = rnd(M, D, seed=4)
     want_dx = dx0.clone()
@@ -167,8 +166,8 @@ def test_cosine_rows_bwd_matches_autograd():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_colsum_relu_bwd(dtype):
-    x = rnd(203, 72, seed=21, dtype=dtype)
-    y = rnd(203, 72, seed=22, dtype=dtype)
+    x = rnd(203, 40, seed=21, dtype=dtype)
+    y = rnd(203, 40, seed=22, dtype=dtype)
     with _hipemu.emulated() as hip:
         cs, rb = hip.colsum(x), hip.relu_bwd(x, y)
     close(cs, C.colsum(x), 1e-5, "colsum")
@@ -203,7 +202,7 @@ def test_adamw_and_sumsq(p16):
 
 
 def test_llama_backward_on_emulated_kernels():
-    """llama_forward_taped + CE + llama_backward on a small Llama (2 layers, 2 heads x 128, vocab 256, right-padded batch) with every
+    """llama_forward_taped + CE + llama_backward on a small Llama (1 layer, 2 heads x 128, vocab 256, right-padded batch) with every
     training entry point on the emulated kernels (forward entry points stay on the contract backend): real strides, alignments and
     workspaces go through the C entry points' argument checks; result == the same graph on the contract backend."""
     from stllm_amd import hip, runtime, synth, training
@@ -211,7 +210,7 @@ def test_llama_backward_on_emulated_kernels():
     train_names = ["transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu", "swiglu_bwd", "rope_bwd", "attention_bwd",
                    "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum", "relu_bwd", "bcast_add_t", "adamw", "sumsq"]
     real = {n: getattr(hip, n) for n in train_names}
-    model = STLLMForCausalLM(StllmConfig(hidden_size=256, intermediate_size=384, num_hidden_layers=2, num_attention_heads=2,
+    model = STLLMForCausalLM(StllmConfig(hidden_size=256, intermediate_size=384, num_hidden_layers=1, num_attention_heads=2,
                                          vocab_size=256), device="cpu")
     synth.fill_module_(model, 0, "")
     B, S = 2, 40
@@ -260,3 +259,37 @@ def test_emulated_forward_attention_matches_contract(dtype, shape):
     with _hipemu.emulated() as hip:
         got = hip.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5, causal=shape["causal"], kv_len=kv_len)
     close(got, want, 4 * TOL[dtype] if dtype != torch.float32 else 2e-5, "attention forward (emulated)")
+
+
+# ---- skinny GEMM of the decode regime, incl. the staged M = 5..8 extension (beam search: 5 beams) -----------------------------
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 5), (torch.float16, 6), (torch.bfloat16, 8)])
+def test_gemv_rows_up_to_eight(dtype, M):
+    from stllm_amd import pack
+    N, K = 128, 520                                    # K % 512 != 0: one full 1024-byte step + a ragged one; K % 8 == 0
+    a = rnd(M, K, seed=50, dtype=dtype, scale=0.5)
+    w = rnd(N, K, seed=51, dtype=dtype, scale=0.05)
+    bias = rnd(N, seed=52)
+    resid = rnd(M, N, seed=53)
+    cos, sin = pack.rope_tables(4, 128)
+    with _hipemu.emulated() as hip:
+        if _hipemu.ON_DEVICE:
+            hip.set_option("gemm_gemv", 2)
+        try:
+            cases = {
+                "store": hip.gemm(a, w, dtype=dtype, bias=bias),
+                "resid": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone()),
+                "swiglu": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_SWIGLU),
+                "rope": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_ROPE, rope=(cos[1:2], sin[1:2]), rope_seq=1, rope_cols=128),
+            }
+        finally:
+            if _hipemu.ON_DEVICE:
+                hip.set_option("gemm_gemv", -1)
+    want = {
+        "store": C.gemm(a, w, dtype=dtype, bias=bias),
+        "resid": C.gemm(a, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone()),
+        "swiglu": C.gemm(a, w, dtype=dtype, epilogue=C.EPI_SWIGLU),
+        "rope": C.gemm(a, w, dtype=dtype, epilogue=C.EPI_ROPE, rope=(cos[1:2], sin[1:2]), rope_seq=1, rope_cols=128),
+    }
+    for n in want:
+        tol = 2e-5 if cases[n].dtype == torch.float32 else TOL[dtype]
+        close(cases[n], want[n], tol, f"gemv M={M} {n}")

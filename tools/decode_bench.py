@@ -11,24 +11,29 @@ ap.add_argument("--llm-layers", type=int, default=32)
 ap.add_argument("--vit-depth", type=int, default=1)
 ap.add_argument("--qformer-layers", type=int, default=1)
 ap.add_argument("--tokens", type=int, default=16)
+ap.add_argument("--rows", type=int, default=1, help="sequences decoded together (5 = demo.py's beam search)")
+ap.add_argument("--gemv", type=int, default=-1, help="stllm_set_option('gemm_gemv'): -1 default (M <= 4), 0 off, 2 = up to M = 8")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, args)
 lm = model.model
 S = 576
-emb = torch.randn(1, S, 4096, device=dev) * 0.02
-cache = lm.new_cache(1, S + args.tokens + 8, dev)
+from stllm_amd import hip
+hip.set_option("gemm_gemv", args.gemv)
+R = args.rows
+emb = (torch.randn(1, S, 4096, device=dev) * 0.02).expand(R, S, 4096).contiguous()
+cache = lm.new_cache(R, S + args.tokens + 8, dev)
 hidden, h16 = lm.prefill(emb, None, cache=cache)
-tok = torch.randn(1, 1, 4096, device=dev) * 0.02
+tok = torch.randn(R, 1, 4096, device=dev) * 0.02
 for _ in range(3):
     lm.decode_step(tok, cache)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(args.tokens):
     _, h = lm.decode_step(tok, cache)
-    logits = model.logits_from(h, 1, 1)
+    logits = model.logits_from(h, R, 1)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.tokens * 1e3
 wbytes = sum(p.numel() for n, p in lm.named_parameters() if "layers" in n) * 2 + 32000 * 4096 * 2
-print(f"decode: {ms:.2f} ms/token ({1e3 / ms:.1f} tok/s), weights streamed per token {wbytes / 1e9:.2f} GB => {wbytes / ms / 1e9:.2f} TB/s")
+print(f"decode ({R} rows, gemm_gemv {args.gemv}): {ms:.2f} ms/step ({1e3 / ms:.1f} tok/s), weights streamed per token {wbytes / 1e9:.2f} GB => {wbytes / ms / 1e9:.2f} TB/s")
