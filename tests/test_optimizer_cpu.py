@@ -61,7 +61,7 @@ def _worker(rank, world, port, q):
         norms = []
         for step in range(3):
             norms.append(opt.step(_grads(named, 10 * step + rank)))      # every rank has its own micro-batch gradient
-    q.put((rank, [p.detach().clone() for _, p in named], norms, opt.m.numel()))
+    q.put((rank, [p.detach().numpy().copy() for _, p in named], norms, opt.m.numel()))   # by value: the worker may exit first
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,7 +92,7 @@ def test_zero1_sharded_step_matches_single_process():
         for a, b in zip(rnorms, norms):
             assert abs(a - b) <= 1e-5 * b
         for got, (n, want) in zip(params, named):
-            assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (rank, n, (got - want).abs().max())
+            assert torch.allclose(torch.from_numpy(got), want, rtol=1e-5, atol=1e-6), (rank, n)
 
 
 def test_cosine_schedule_matches_hf():
@@ -133,3 +133,87 @@ def test_optimizer_resume_is_exact():
         assert torch.equal(p, w), n
     with pytest.raises(ValueError):
         training.AdamW(_params()[:2], lr=1e-3).load_state_dict(ckpt_o)
+
+
+# ---- data-parallel training of a small Llama: real gradients + ZeRO-1 step under gloo == one process on the averaged gradients ----
+def _tiny_lm():
+    from stllm_amd import synth
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    m = STLLMForCausalLM(StllmConfig(hidden_size=256, intermediate_size=384, num_hidden_layers=2, num_attention_heads=2, vocab_size=256),
+                         device="cpu")
+    synth.fill_module_(m, 0, "")
+    return m
+
+
+def _lm_named(m):
+    return [(n, p) for n, p in m.named_parameters()]
+
+
+def _lm_grads(model, rank, step):
+    """CE gradients of the micro-batch (rank, step): taped forward + explicit backward on the contract backend"""
+    from stllm_amd import hip, training
+    g = torch.Generator().manual_seed(1000 + 17 * step + rank)
+    B, S = 2, 24
+    ids = torch.randint(0, 256, (B, S), generator=g)
+    emb = model.model.embed_tokens(ids)
+    labels = torch.randint(0, 256, (B * S,), generator=g).to(torch.int32)
+    h32, h16, tape = training.llama_forward_taped(model.model, emb, None)
+    W = model.lm_weight(torch.float32)
+    logits = hip.gemm(h16, W, dtype=torch.float32, out_f32=True)
+    loss = hip.cross_entropy_rows(logits, labels).mean()
+    dlog = hip.cross_entropy_bwd(logits, labels, 1.0 / (B * S), dtype=torch.float32, vocab=256)
+    d_h16, dw = training.linear_bwd(dlog, h16, W, torch.float32)
+    d_emb, grads = training.llama_backward(model.model, tape, d_h16, None)
+    grads["lm_head.weight"] = dw
+    d_table = torch.zeros_like(model.model.embed_tokens.weight)
+    hip.scatter_add_rows(d_emb, (-(ids.reshape(-1)) - 1).to(torch.int32), d_table, d_table)
+    grads["model.embed_tokens.weight"] = d_table
+    return loss.item(), grads
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stllm_amd import runtime, training
+    torch.set_grad_enabled(False)
+    model = _tiny_lm()
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        opt = training.AdamW(_lm_named(model), lr=1e-2, max_grad_norm=1.0, group=dist.group.WORLD, world_size=world, rank=rank)
+        losses = []
+        for step in range(3):
+            loss, grads = _lm_grads(model, rank, step)
+            opt.step(grads)
+            model._lm_packed = {}
+            model.model.repack()
+            losses.append(loss)
+    q.put((rank, losses, {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))   # by value: the worker may exit first
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_llama_training_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from stllm_amd import runtime, training
+    torch.set_grad_enabled(False)
+    model = _tiny_lm()
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        opt = training.AdamW(_lm_named(model), lr=1e-2, max_grad_norm=1.0)
+        for step in range(3):
+            (l0, g0), (l1, g1) = _lm_grads(model, 0, step), _lm_grads(model, 1, step)
+            assert abs(l0 - res[0][1][step]) < 1e-5 and abs(l1 - res[1][1][step]) < 1e-5      # same weights on every rank, every step
+            opt.step({n: (g0[n] + g1[n]) / 2 for n in g0})
+            model._lm_packed = {}
+            model.model.repack()
+    for rank, _, params in res:
+        for n, p in model.named_parameters():
+            assert torch.allclose(torch.from_numpy(params[n]), p, rtol=1e-5, atol=1e-6), (rank, n)
