@@ -294,16 +294,27 @@ constexpr int kRowPitch = kD * 2 + 16;  // bytes per row-major tile row in LDS (
 constexpr int kTPitch = 32 * 2 + 8;     // bytes per row of a transposed tile [d][32 rows]
 constexpr float kNegBig = -1.0e30f;
 
-// stage rows [row0, row0 + 32) of head (b, h): row-major copy (rows_lds) and, if t_lds, the transposed copy [d][row]
+// Tiles are register-staged one tile AHEAD (as in the forward kernel): fetch_tile16 issues the global loads of the next tile before the
+// MFMA work of the current one, put_tile16 writes them to LDS at the top of the next iteration — HBM / L2 latency hides under compute.
+constexpr int kCPT = (32 * (kD / 8)) / (64 * kNW);      // 16-byte chunks per thread and tile
 template <typename T>
-__device__ __forceinline__ void stage_tile16(char* rows_lds, char* t_lds, const Ptr& t, int b, int h, int row0, int S, int tid) {
+__device__ __forceinline__ void fetch_tile16(i32x4* reg, const Ptr& t, int b, int h, int row0, int S, int tid) {
   const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)h * kD) * 2;
 #pragma unroll
-  for (int c = 0; c < (32 * (kD / 8)) / (64 * kNW); ++c) {
+  for (int c = 0; c < kCPT; ++c) {
     const int ch = tid + c * 64 * kNW;
     const int cc = ch >> 5, row = ch & 31;      // consecutive lanes = consecutive rows: conflict-free transposed writes
-    i32x4 x = {0, 0, 0, 0};
-    if (row0 + row < S) x = *reinterpret_cast<const i32x4*>(base + ((int64_t)(row0 + row) * t.rs + cc * 8) * 2);
+    const i32x4 z = {0, 0, 0, 0};
+    reg[c] = (row0 + row < S) ? *reinterpret_cast<const i32x4*>(base + ((int64_t)(row0 + row) * t.rs + cc * 8) * 2) : z;
+  }
+}
+// row-major copy (rows_lds) and, if t_lds, the transposed copy [d][row]
+__device__ __forceinline__ void put_tile16(const i32x4* reg, char* rows_lds, char* t_lds, int tid) {
+#pragma unroll
+  for (int c = 0; c < kCPT; ++c) {
+    const int ch = tid + c * 64 * kNW;
+    const int cc = ch >> 5, row = ch & 31;
+    const i32x4 x = reg[c];
     *reinterpret_cast<i32x4*>(rows_lds + row * kRowPitch + cc * 16) = x;
     if (t_lds) {
 #pragma unroll
@@ -406,10 +417,13 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   }
   // ---- sweep 1: log-sum-exp of the scaled scores, log2 domain ------------------------------------------------------------
   float m_run = kNegBig, l_run = 0.0f;
+  i32x4 kreg[kCPT], vreg[kCPT];
+  if (kv_end > 0) fetch_tile16<T>(kreg, k, b, h, 0, S, tid);
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
+    __syncthreads();                       // previous tile fully consumed
+    put_tile16(kreg, k_lds, nullptr, tid);
     __syncthreads();
-    stage_tile16<T>(k_lds, nullptr, k, b, h, kv0, S, tid);
-    __syncthreads();
+    if (kv0 + 32 < kv_end) fetch_tile16<T>(kreg, k, b, h, kv0 + 32, S, tid);
     if (causal && kv0 > wave_q_last) continue;
     f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
     float mx = kNegBig;
@@ -441,11 +455,19 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   for (int i = 0; i < kDB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  if (kv_end > 0) {
+    fetch_tile16<T>(kreg, k, b, h, 0, S, tid);
+    fetch_tile16<T>(vreg, v, b, h, 0, S, tid);
+  }
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();
-    stage_tile16<T>(k_lds, kt_lds, k, b, h, kv0, S, tid);
-    stage_tile16<T>(v_lds, nullptr, v, b, h, kv0, S, tid);
+    put_tile16(kreg, k_lds, kt_lds, tid);
+    put_tile16(vreg, v_lds, nullptr, tid);
     __syncthreads();
+    if (kv0 + 32 < kv_end) {
+      fetch_tile16<T>(kreg, k, b, h, kv0 + 32, S, tid);
+      fetch_tile16<T>(vreg, v, b, h, kv0 + 32, S, tid);
+    }
     if (causal && kv0 > wave_q_last) continue;
     f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
     const f32x16 dp = tile_nt<T>(v_lds, dof, li, lh);
@@ -485,12 +507,22 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
 #pragma unroll
     for (int r = 0; r < 16; ++r) accv[i][r] = acck[i][r] = 0.0f;
   const float* wrow = ws + (int64_t)(b * H + h) * S * 2;
-  for (int q0 = causal ? k_blk0 : 0; q0 < S; q0 += 32) {
+  const int q_first = causal ? k_blk0 : 0;
+  i32x4 qreg[kCPT], oreg[kCPT];
+  float streg = 0.0f;
+  auto fetch = [&](int q0) {
+    fetch_tile16<T>(qreg, q, b, h, q0, S, tid);
+    fetch_tile16<T>(oreg, dO, b, h, q0, S, tid);
+    if (tid < 64) streg = (q0 + (tid >> 1) < S) ? wrow[2 * (q0 + (tid >> 1)) + (tid & 1)] : 0.0f;
+  };
+  if (q_first < S) fetch(q_first);
+  for (int q0 = q_first; q0 < S; q0 += 32) {
     __syncthreads();
-    stage_tile16<T>(q_lds, qt_lds, q, b, h, q0, S, tid);
-    stage_tile16<T>(do_lds, dot_lds, dO, b, h, q0, S, tid);
-    if (tid < 64) st_lds[tid] = (q0 + (tid >> 1) < S) ? wrow[2 * (q0 + (tid >> 1)) + (tid & 1)] : 0.0f;
+    put_tile16(qreg, q_lds, qt_lds, tid);
+    put_tile16(oreg, do_lds, dot_lds, tid);
+    if (tid < 64) st_lds[tid] = streg;
     __syncthreads();
+    if (q0 + 32 < S) fetch(q0 + 32);
     if (causal && q0 + 31 < wave_k_first) continue;          // every query of the tile precedes every key of this wave
     f32x16 s = tile_nt<T>(q_lds, kf, li, lh);                // s[r] = S[query (r&3)+8(r>>2)+4lh][key krow]
     f32x16 ds = tile_nt<T>(do_lds, vf, li, lh);              // dP, same layout
