@@ -1,6 +1,6 @@
 // TEST-ONLY host emulation of the small HIP surface used by train_ops.hip / attention_bwd.hip, so that the LOGIC of those
 // kernels (indexing, reductions, barriers, masks) is checked by the CPU suite against the contract backend
-// (tests/test_train_kernels_emulated_cpu.py).  One OS thread per HIP thread, blocks run one after another;
+// (tests/test_kernels_emulated_cpu.py).  One OS thread per HIP thread, blocks run one after another;
 // __syncthreads = std::barrier over the block, wave shuffles = exchange buffer + per-wave barrier (64 lanes).
 // Nothing in st-llm_amd/ includes this file; it says nothing about performance or ISA-level behaviour.
 #pragma once

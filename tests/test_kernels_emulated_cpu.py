@@ -293,3 +293,38 @@ def test_gemv_rows_up_to_eight(dtype, M):
     for n in want:
         tol = 2e-5 if cases[n].dtype == torch.float32 else TOL[dtype]
         close(cases[n], want[n], tol, f"gemv M={M} {n}")
+
+
+# ---- forward streaming kernels (norm.hip, elementwise.hip; parity-green on the device): CPU regression net for future edits ----
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_emulated_forward_norms(dtype):
+    x, g, b = rnd(9, 264, seed=60) * 2 + 0.1, rnd(264, seed=61) + 1, rnd(264, seed=62)
+    with _hipemu.emulated() as hip:
+        ln_t, ln_f = hip.layernorm(x, g, b, 1e-5, dtype=dtype, want_f32=True)
+        rm_t, rm_f = hip.rmsnorm(x, g, 1e-6, dtype=dtype, want_f32=True)
+    wl_t, wl_f = C.layernorm(x, g, b, 1e-5, dtype=dtype, want_f32=True)
+    wr_t, wr_f = C.rmsnorm(x, g, 1e-6, dtype=dtype, want_f32=True)
+    for got, want, tol in ((ln_t, wl_t, TOL[dtype]), (ln_f, wl_f, 1e-5), (rm_t, wr_t, TOL[dtype]), (rm_f, wr_f, 1e-5)):
+        close(got, want, tol, "norm")
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+def test_emulated_forward_elementwise():
+    a, bsrc, add = rnd(6, 40, seed=63), rnd(5, 40, seed=64), rnd(3, 40, seed=65)
+    idx = torch.tensor([0, -1, 5, -5, 2, 2, -3], dtype=torch.int32)
+    idx_add = torch.tensor([0, 1, 2, 0, 1, 2, 0], dtype=torch.int32)
+    x3 = rnd(2, 3, 40, seed=66)
+    logits = rnd(5, 300, seed=67, scale=3.0)
+    labels = torch.tensor([3, -100, 299, 0, 17], dtype=torch.int32)
+    with _hipemu.emulated() as hip:
+        g = hip.gather_rows(a, idx, src_b=bsrc, add=add, idx_add=idx_add, scale=0.5)
+        m = hip.mean_t(x3)
+        cs = hip.cosine_rows(a, bsrc, None, torch.tensor([4, 0, 1, 1, 2, 3], dtype=torch.int32), n_rows=6)
+        ce = hip.cross_entropy_rows(logits, labels)
+        c16 = hip.cast_rows(a, torch.bfloat16)
+    close(g, C.gather_rows(a, idx, src_b=bsrc, add=add, idx_add=idx_add, scale=0.5), 1e-6, "gather_rows")
+    close(m, C.mean_t(x3), 1e-6, "mean_t")
+    close(cs, C.cosine_rows(a, bsrc, None, torch.tensor([4, 0, 1, 1, 2, 3], dtype=torch.int32), n_rows=6), 1e-5, "cosine_rows")
+    close(ce, C.cross_entropy_rows(logits, labels), 1e-5, "cross_entropy_rows")
+    assert torch.equal(c16, a.to(torch.bfloat16))

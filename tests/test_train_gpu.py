@@ -1,12 +1,12 @@
 """GPU (-m gpu): the training entry points on the device.
 
 These kernels were written after round 1's GPU minutes were spent: their logic is covered on the CPU by the emulated build
-(tests/test_train_kernels_emulated_cpu.py) and the host graph by tests/test_backward_cpu.py, but THIS file had not run on
+(tests/test_kernels_emulated_cpu.py) and the host graph by tests/test_backward_cpu.py, but THIS file had not run on
 hardware when it was committed.  Hence (a) every check runs in a child process with a timeout, so that a device fault cannot
 take the rest of the GPU suite down, and (b) the tests are xfail(strict=False): XPASS = parity on the device, XFAIL = work
 for the next round.  Remove the marker once they have passed on an MI355X.
 
-1. every kernel case of test_train_kernels_emulated_cpu.py, through the real C ABI on cuda:0 (same tolerances);
+1. every kernel case of test_kernels_emulated_cpu.py, through the real C ABI on cuda:0 (same tolerances);
 2. loss_and_grads on the device against the reference's gradient fixture (fp32 mode, 3e-4 of each tensor's abs-max), and
    bf16 mode against the same fixture with the tolerance of bf16 GEMM operands (cosine similarity of every gradient tensor
    >= 0.995, loss within 2e-2)."""
@@ -31,7 +31,7 @@ def _child(args, timeout, env_extra=None):
 @pytest.mark.gpu
 @FIRST_RUN
 def test_training_kernels_on_device():
-    out = _child(["-m", "pytest", "tests/test_train_kernels_emulated_cpu.py", "-q", "-x", "-k", "not emulated_kernels", "-p", "no:cacheprovider"],
+    out = _child(["-m", "pytest", "tests/test_kernels_emulated_cpu.py", "-q", "-x", "-k", "not emulated_kernels", "-p", "no:cacheprovider"],
                  timeout=900, env_extra={"STLLM_TRAIN_KERNELS_ON_DEVICE": "1"})
     assert " passed" in out and "failed" not in out, out[-2000:]
 
