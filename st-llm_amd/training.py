@@ -19,7 +19,9 @@ MI355X-first choices:
     needs no recomputation of the largest GEMM;
   * q/k gradients are rotated back by `stllm_rope_bwd` in the packed head layout, weight gradients are produced in the packed
     layouts of pack.py and un-permuted once per step into the reference's parameter layout (index permutations only).
-BT-Adapter parameters (model_type *_btadapter) are not differentiated yet: `backward` raises for that backbone.
+BT-Adapter parameters (model_type *_btadapter — 4 of the 5 shipped training configs) are not differentiated yet: their gradient
+needs the backward through the frozen Q-Former.  `loss_and_grads(..., freeze_btadapter=True)` trains everything else on that
+backbone with the adapter frozen; without the flag it raises.
 
 Layout of the result: {reference parameter name: fp32 gradient in the reference's layout}.
 """
@@ -174,13 +176,16 @@ def _acc(grads, name, g):
     grads[name] = g if name not in grads else grads[name] + g
 
 
-def loss_and_grads(model, samples):
-    """model: STLLMForCausalLM.  Returns (loss fp32 scalar tensor, loss_mvm or None, grads {reference name: fp32 tensor})."""
+def loss_and_grads(model, samples, freeze_btadapter=False):
+    """model: STLLMForCausalLM.  Returns (loss fp32 scalar tensor, loss_mvm or None, grads {reference name: fp32 tensor}).
+    freeze_btadapter: accept the eva_btadapter_g backbone with its adapter treated as frozen (the reference trains the `BTAdapter*`
+    parameters too, st_llm.py:257-261; their gradient needs the backward THROUGH the frozen Q-Former, which is not built yet)."""
     lmw = model                                  # lm_head owner
     lm = model.model                             # STLLMLlamaModel (LlamaModel + stllm_model)
     sm = lm.stllm_model
-    if sm.vit_model != "eva_clip_g":
-        raise NotImplementedError("BT-Adapter parameters are not differentiated yet (SURVEY.md §8f rank 3, adapter part)")
+    if sm.vit_model != "eva_clip_g" and not freeze_btadapter:
+        raise NotImplementedError("BT-Adapter parameters are not differentiated yet (SURVEY.md §8f rank 3, adapter part): pass "
+                                  "freeze_btadapter=True to train everything else with the adapter frozen")
     if sm.frame_parallel is not None:
         raise NotImplementedError("training is data-parallel (one micro-batch per rank); frame-parallel is the inference path")
     dt = runtime.compute_dtype()
@@ -294,7 +299,8 @@ def loss_and_grads(model, samples):
 
 # ---- optimizer --------------------------------------------------------------------------------------------------------
 def trainable_parameters(model):
-    """(name, parameter) of what the reference leaves trainable (st_llm.py:182-186, 257-296 with the shipped configs)."""
+    """(name, parameter) of what the reference leaves trainable (st_llm.py:182-186, 257-296 with the shipped configs) — minus the
+    `visual_encoder.BTAdapter*` parameters of the eva_btadapter_g backbone, which `loss_and_grads` does not differentiate yet."""
     frozen = ("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
               "model.stllm_model.query_tokens")
     seen = set()
@@ -405,9 +411,9 @@ def trainable_state_dict(model):
     return {n: p.detach().clone() for n, p in trainable_parameters(model)}
 
 
-def train_step(model, samples, optimizer):
+def train_step(model, samples, optimizer, freeze_btadapter=False):
     """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1)."""
-    loss, loss_mvm, grads = loss_and_grads(model, samples)
+    loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter)
     norm = optimizer.step(grads)
     invalidate_packed(model)
     return loss, loss_mvm, norm

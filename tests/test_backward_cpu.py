@@ -142,3 +142,26 @@ def test_mean_pooling_backward_and_one_optimizer_step():
         assert not torch.equal(before, model.lm_head.weight)
         l1 = model(samples=samples).loss
     assert l1.item() < l0.item() - 0.05, (l0.item(), l1.item())
+
+
+def test_btadapter_backbone_with_frozen_adapter():
+    """eva_btadapter_g backbone (4 of the 5 shipped training configs): everything but the adapter is differentiated
+    (freeze_btadapter=True) and matches autograd over the oracle with the visual encoder held constant; without the flag the
+    call refuses rather than silently dropping the adapter's gradients."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build, make_inputs
+    from stllm_amd import runtime, training
+    cfg = CFGS["btadapter"]
+    model = build(cfg, vit_depth=4, qf_layers=2, llm_layers=1)
+    samples, osamples = make_inputs(2, 4, False)
+    sd = sd_from({**shapes.stllm_model_shapes(4, 2, False, cfg["video_input"], cfg["mvm_decode"], vit_model=cfg["vit_model"], qf_vocab=32000),
+                  **shapes.llama_shapes(1)})
+    want_loss, want = oracle_grads(cfg, sd, osamples)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        with pytest.raises(NotImplementedError):
+            training.loss_and_grads(model, samples)
+        loss, _, grads = training.loss_and_grads(model, samples, freeze_btadapter=True)
+    assert abs(loss.item() - want_loss) <= 1e-4
+    assert set(grads) == set(want) == {n for n, _ in training.trainable_parameters(model)}
+    for n, gr in grads.items():
+        assert (gr - want[n]).abs().max().item() <= 3e-4 * want[n].abs().max().item(), n
