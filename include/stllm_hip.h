@@ -253,15 +253,17 @@ int stllm_swiglu_bwd(int dtype, const void* gu, int64_t ldgu, const void* dg, in
 int stllm_rope_bwd(int dtype, void* d, int64_t ld, const float* cos_t, const float* sin_t, int rows, int cols, int rope_seq,
                    int rope_cols, void* stream);
 
-/* Gradients of stllm_attention for the Llama prefill (Sq == Skv == S, D == 128): dq, dk, dv from q, k, v, the forward output
- * o and its gradient dO; same element addressing as stllm_attention for all eight operands; masks as in the forward.
- * workspace: stllm_attention_bwd_workspace_bytes(B, H, S) (log-sum-exp and dO.o per query row). */
-int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int S);
+/* Gradients of stllm_attention: dq, dk, dv from q, k, v, the forward output o and its gradient dO; same element addressing as
+ * stllm_attention for all eight operands; masks as in the forward (causal needs Sq == Skv).  D % 8 == 0, D <= 128.
+ * bf16 / f16 with D == 128 and Sq == Skv (the Llama prefill) run on MFMA kernels, everything else (fp32, the Q-Former's 64-wide
+ * heads and cross-attention, EVA's 88-wide heads) on the fp32-FMA kernels.
+ * workspace: stllm_attention_bwd_workspace_bytes(B, H, Sq) (log-sum-exp and dO.o per query row). */
+int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int Sq);
 int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                         const void* v, int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs,
                         const void* dO, int64_t do_bs, int64_t do_rs, void* dq, int64_t dq_bs, int64_t dq_rs,
                         void* dk, int64_t dk_bs, int64_t dk_rs, void* dv, int64_t dv_bs, int64_t dv_rs,
-                        int B, int H, int S, int D, float scale, int causal, const int32_t* kv_len,
+                        int B, int H, int Sq, int Skv, int D, float scale, int causal, const int32_t* kv_len,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Transpose of stllm_cross_entropy_rows summed with weight `scale` (st_llm.py:127-135; scale = 1 / #valid rows):
@@ -286,6 +288,12 @@ int stllm_colsum(int dtype, const void* x, int64_t ldx, float* out, int rows, in
 
 /* dx = dy * (y > 0)  — the ReLU between down_proj and up_proj (st_llm.py:473-475); cols % 8 == 0. */
 int stllm_relu_bwd(int dtype, const void* dy, int64_t lddy, const void* y, int64_t ldy, void* dx, int64_t lddx, int rows, int cols,
+                   void* stream);
+
+/* exact-erf GELU (nn.GELU(), eva_vit.py:45; Qformer.py:347 ACT2FN["gelu"]) on RAW pre-activations and its derivative: training keeps the
+ * pre-activations (STORE epilogue) because the fused GELU epilogue of the forward does not.  cols % 8 == 0. */
+int stllm_gelu(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, int rows, int cols, void* stream);
+int stllm_gelu_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int rows, int cols,
                    void* stream);
 
 /* Transpose of stllm_mean_t up to the 1/T factor: dst[b, t, j] += scale * src[b, j]  (f32, J % 4 == 0). */

@@ -1,5 +1,5 @@
 // Attention backward for the training step: gradients of  O = softmax(scale * Q K^T + masks) V
-// for head_dim 128, causal and / or key-length masked (right-padded batches), operands in the strided fused-QKV layout of
+// causal and / or key-length masked (right-padded batches), operands in the strided fused-QKV layout of
 // the forward kernels (include/stllm_hip.h: element (b, s, h, d) at base[b * batch_stride + s * row_stride + h * D + d]).
 //
 // Flash-attention-2 backward structure, three kernels, nothing S x S ever touches HBM:
@@ -27,10 +27,8 @@
 
 namespace {
 
-constexpr int kD = 128;       // head dim
+constexpr int kD = 128;       // head dim of the MFMA path (Llama)
 constexpr int kT = 32;        // tile edge (queries / keys)
-constexpr int kLd = 132;      // LDS row stride in floats
-constexpr int kTile = kT * kLd;
 
 template <typename T> __device__ __forceinline__ void ld8(const void* base, int64_t idx, float* f) {
   if constexpr (Elem<T>::kIsF32) {
@@ -47,44 +45,34 @@ template <typename T> __device__ __forceinline__ void ld8(const void* base, int6
     }
   }
 }
-template <typename T> __device__ __forceinline__ void st8(void* base, int64_t idx, const float* f) {
-  if constexpr (Elem<T>::kIsF32) {
-    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx);
-    p[0] = make_float4(f[0], f[1], f[2], f[3]);
-    p[1] = make_float4(f[4], f[5], f[6], f[7]);
-  } else {
-    uint4 u;
-    u.x = Elem<T>::pack2(f[0], f[1]); u.y = Elem<T>::pack2(f[2], f[3]);
-    u.z = Elem<T>::pack2(f[4], f[5]); u.w = Elem<T>::pack2(f[6], f[7]);
-    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + idx) = u;
-  }
-}
 
 struct Ptr { const void* p; int64_t bs, rs; };
 struct MPtr { void* p; int64_t bs, rs; };
 
-// rows [row0, row0 + 32) of head (b, h) -> lds[32][kLd] as fp32, zero beyond S
-template <typename T>
-__device__ __forceinline__ void load_tile(float* lds, const Ptr& t, int b, int h, int row0, int S, int tid) {
-  const int64_t off = (int64_t)b * t.bs + (int64_t)h * kD;
-  for (int v = tid; v < kT * (kD / 8); v += 256) {
-    const int r = v >> 4, c = (v & 15) * 8;
+// ---- VALU path: any head dim D <= DP (DP in {64, 96, 128}; 88 is zero-padded to 96 in LDS only), Sq != Skv allowed ------------
+// rows [row0, row0 + 32) of head (b, h) -> lds[32][DP + 4] as fp32, zero beyond `rows` and beyond D
+template <typename T, int DP>
+__device__ __forceinline__ void load_tile(float* lds, const Ptr& t, int b, int h, int D, int row0, int rows, int tid) {
+  constexpr int LD = DP + 4, CPR = DP / 8;
+  const int64_t off = (int64_t)b * t.bs + (int64_t)h * D;
+  for (int v = tid; v < kT * CPR; v += 256) {
+    const int r = v / CPR, c = (v % CPR) * 8;
     float f[8];
-    if (row0 + r < S) ld8<T>(t.p, off + (int64_t)(row0 + r) * t.rs + c, f);
+    if (row0 + r < rows && c < D) ld8<T>(t.p, off + (int64_t)(row0 + r) * t.rs + c, f);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = 0.0f;
     }
-    float4* d = reinterpret_cast<float4*>(lds + r * kLd + c);
+    float4* d = reinterpret_cast<float4*>(lds + r * LD + c);
     d[0] = make_float4(f[0], f[1], f[2], f[3]);
     d[1] = make_float4(f[4], f[5], f[6], f[7]);
   }
 }
 
-__device__ __forceinline__ float dot128(const float* a, const float* b) {
+template <int DP> __device__ __forceinline__ float dot_dp(const float* a, const float* b) {
   float s = 0.0f;
 #pragma unroll 8
-  for (int d = 0; d < kD; d += 4) {
+  for (int d = 0; d < DP; d += 4) {
     const float4 x = *reinterpret_cast<const float4*>(a + d), y = *reinterpret_cast<const float4*>(b + d);
     s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
   }
@@ -98,30 +86,40 @@ __device__ __forceinline__ float oct_max(float v) {
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
   return v;
 }
+// this thread's DP/8 consecutive dims of one output row (d < D only)
+template <typename T, int DP>
+__device__ __forceinline__ void store_dims(const MPtr& t, int b, int h, int D, int row, int d0, const float* acc, float mul) {
+  const int64_t off = (int64_t)b * t.bs + (int64_t)row * t.rs + (int64_t)h * D;
+#pragma unroll
+  for (int e = 0; e < DP / 8; ++e)
+    if (d0 + e < D) store_elem<T>(t.p, off + d0 + e, acc[e] * mul);
+}
+
+struct BwdDims { int H, Sq, Skv, D; float scale; int causal; const int32_t* kv_len; };
 
 // ---- 1. statistics -------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(Ptr q, Ptr k, Ptr o, Ptr dO, float* __restrict__ ws, int H, int S, float scale,
-                                                             int causal, const int32_t* __restrict__ kv_len) {
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(Ptr q, Ptr k, Ptr o, Ptr dO, float* __restrict__ ws, BwdDims p) {
+  constexpr int LD = DP + 4, DPT = DP / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Ks = smem + kTile;
+  float* Ks = smem + kT * LD;
   const int tid = threadIdx.x, qi = tid >> 3, kg = tid & 7;
   const int q0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
-  const int kmax = kv_len ? min(S, kv_len[b]) : S;
-  const int kend = causal ? min(kmax, q0 + kT) : kmax;
-  load_tile<T>(Qs, q, b, h, q0, S, tid);
+  const int kmax = p.kv_len ? min(p.Skv, p.kv_len[b]) : p.Skv;
+  const int kend = p.causal ? min(kmax, q0 + kT) : kmax;
+  load_tile<T, DP>(Qs, q, b, h, p.D, q0, p.Sq, tid);
   float m = -3.0e38f, l = 0.0f;
   for (int k0 = 0; k0 < kend; k0 += kT) {
     __syncthreads();
-    load_tile<T>(Ks, k, b, h, k0, S, tid);
+    load_tile<T, DP>(Ks, k, b, h, p.D, k0, p.Skv, tid);
     __syncthreads();
     float s[4], mt = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kj = kg * 4 + t, kk = k0 + kj;
-      const bool ok = kk < kend && (!causal || kk <= q0 + qi);
-      s[t] = ok ? dot128(Qs + qi * kLd, Ks + kj * kLd) * scale : -3.0e38f;
+      const bool ok = kk < kend && (!p.causal || kk <= q0 + qi);
+      s[t] = ok ? dot_dp<DP>(Qs + qi * LD, Ks + kj * LD) * p.scale : -3.0e38f;
       mt = fmaxf(mt, s[t]);
     }
     mt = oct_max(mt);
@@ -132,65 +130,62 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(Ptr q, Ptr k, Ptr o
     ps = oct_sum(ps);
     if (mn > -1.0e38f) { l = l * __expf(m - mn) + ps; m = mn; }
   }
-  // delta = dO . O over this thread's 16 of the 128 dims
+  // delta = dO . O over this thread's DPT of the DP dims
   float dl = 0.0f;
-  if (q0 + qi < S) {
-    const int64_t oo = (int64_t)b * o.bs + (int64_t)(q0 + qi) * o.rs + (int64_t)h * kD + kg * 16;
-    const int64_t od = (int64_t)b * dO.bs + (int64_t)(q0 + qi) * dO.rs + (int64_t)h * kD + kg * 16;
-    float a[8], c[8];
+  if (q0 + qi < p.Sq) {
+    const int64_t oo = (int64_t)b * o.bs + (int64_t)(q0 + qi) * o.rs + (int64_t)h * p.D;
+    const int64_t od = (int64_t)b * dO.bs + (int64_t)(q0 + qi) * dO.rs + (int64_t)h * p.D;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      ld8<T>(o.p, oo + half * 8, a);
-      ld8<T>(dO.p, od + half * 8, c);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dl = fmaf(a[e], c[e], dl);
+    for (int e = 0; e < DPT; ++e) {
+      const int d = kg * DPT + e;
+      if (d < p.D) dl = fmaf(load_elem<T>(o.p, oo + d), load_elem<T>(dO.p, od + d), dl);
     }
   }
   dl = oct_sum(dl);
-  if (kg == 0 && q0 + qi < S) {
-    float* w = ws + ((int64_t)(b * H + h) * S + q0 + qi) * 2;
+  if (kg == 0 && q0 + qi < p.Sq) {
+    float* w = ws + ((int64_t)(b * p.H + h) * p.Sq + q0 + qi) * 2;
     w[0] = m + __logf(l);
     w[1] = dl;
   }
 }
 
 // ---- 2. dQ -----------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dq, const float* __restrict__ ws, int H, int S,
-                                                          float scale, int causal, const int32_t* __restrict__ kv_len) {
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dq, const float* __restrict__ ws, BwdDims p) {
+  constexpr int LD = DP + 4, DPT = DP / 8, TILE = kT * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Os = smem + kTile;
-  float* Ks = smem + 2 * kTile;
-  float* Vs = smem + 3 * kTile;
-  float* Ds = smem + 4 * kTile;            // [32][33]
+  float* Os = smem + TILE;
+  float* Ks = smem + 2 * TILE;
+  float* Vs = smem + 3 * TILE;
+  float* Ds = smem + 4 * TILE;            // [32][33]
   const int tid = threadIdx.x, qi = tid >> 3, kg = tid & 7;
   const int q0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
-  const int kmax = kv_len ? min(S, kv_len[b]) : S;
-  const int kend = causal ? min(kmax, q0 + kT) : kmax;
-  load_tile<T>(Qs, q, b, h, q0, S, tid);
-  load_tile<T>(Os, dO, b, h, q0, S, tid);
+  const int kmax = p.kv_len ? min(p.Skv, p.kv_len[b]) : p.Skv;
+  const int kend = p.causal ? min(kmax, q0 + kT) : kmax;
+  load_tile<T, DP>(Qs, q, b, h, p.D, q0, p.Sq, tid);
+  load_tile<T, DP>(Os, dO, b, h, p.D, q0, p.Sq, tid);
   float lse = 0.0f, delta = 0.0f;
-  if (q0 + qi < S) {
-    const float* w = ws + ((int64_t)(b * H + h) * S + q0 + qi) * 2;
+  if (q0 + qi < p.Sq) {
+    const float* w = ws + ((int64_t)(b * p.H + h) * p.Sq + q0 + qi) * 2;
     lse = w[0]; delta = w[1];
   }
-  float acc[16];
+  float acc[DPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  for (int e = 0; e < DPT; ++e) acc[e] = 0.0f;
   for (int k0 = 0; k0 < kend; k0 += kT) {
     __syncthreads();
-    load_tile<T>(Ks, k, b, h, k0, S, tid);
-    load_tile<T>(Vs, v, b, h, k0, S, tid);
+    load_tile<T, DP>(Ks, k, b, h, p.D, k0, p.Skv, tid);
+    load_tile<T, DP>(Vs, v, b, h, p.D, k0, p.Skv, tid);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int kj = kg * 4 + t, kk = k0 + kj;
-      const bool ok = kk < kend && (!causal || kk <= q0 + qi) && q0 + qi < S;
+      const bool ok = kk < kend && (!p.causal || kk <= q0 + qi) && q0 + qi < p.Sq;
       float ds = 0.0f;
       if (ok) {
-        const float s = dot128(Qs + qi * kLd, Ks + kj * kLd) * scale;
-        const float dp = dot128(Os + qi * kLd, Vs + kj * kLd);
+        const float s = dot_dp<DP>(Qs + qi * LD, Ks + kj * LD) * p.scale;
+        const float dp = dot_dp<DP>(Os + qi * LD, Vs + kj * LD);
         ds = __expf(s - lse) * (dp - delta);
       }
       Ds[qi * 33 + kj] = ds;
@@ -199,90 +194,78 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(Ptr q, Ptr k, Ptr v, P
 #pragma unroll 4
     for (int j = 0; j < kT; ++j) {
       const float w = Ds[qi * 33 + j];
-      const float* kr = Ks + j * kLd + kg * 16;
+      const float* kr = Ks + j * LD + kg * DPT;
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) {
+      for (int e = 0; e < DPT; e += 4) {
         const float4 x = *reinterpret_cast<const float4*>(kr + e);
         acc[e] = fmaf(w, x.x, acc[e]); acc[e + 1] = fmaf(w, x.y, acc[e + 1]);
         acc[e + 2] = fmaf(w, x.z, acc[e + 2]); acc[e + 3] = fmaf(w, x.w, acc[e + 3]);
       }
     }
   }
-  if (q0 + qi < S) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] *= scale;
-    const int64_t off = (int64_t)b * dq.bs + (int64_t)(q0 + qi) * dq.rs + (int64_t)h * kD + kg * 16;
-    st8<T>(dq.p, off, acc);
-    st8<T>(dq.p, off + 8, acc + 8);
-  }
+  if (q0 + qi < p.Sq) store_dims<T, DP>(dq, b, h, p.D, q0 + qi, kg * DPT, acc, p.scale);
 }
 
 // ---- 3. dK, dV ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws, int H,
-                                                           int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
+template <typename T, int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws,
+                                                           BwdDims p) {
+  constexpr int LD = DP + 4, DPT = DP / 8, TILE = kT * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
-  float* Os = smem + kTile;
-  float* Ks = smem + 2 * kTile;
-  float* Vs = smem + 3 * kTile;
-  float* Ps = smem + 4 * kTile;            // [32 q][33]
-  float* Ds = Ps + kT * 33;                // [32 q][33]
+  float* Os = smem + TILE;
+  float* Ks = smem + 2 * TILE;
+  float* Vs = smem + 3 * TILE;
+  float* Ps = smem + 4 * TILE;            // [32 q][33]
+  float* Ds = Ps + kT * 33;               // [32 q][33]
   const int tid = threadIdx.x, kj = tid >> 3, qg = tid & 7;
   const int k0 = blockIdx.x * kT, h = blockIdx.y, b = blockIdx.z;
-  const int kmax = kv_len ? min(S, kv_len[b]) : S;
+  const int kmax = p.kv_len ? min(p.Skv, p.kv_len[b]) : p.Skv;
   const int kk = k0 + kj;
-  load_tile<T>(Ks, k, b, h, k0, S, tid);
-  load_tile<T>(Vs, v, b, h, k0, S, tid);
-  float av[16], ak[16];
+  load_tile<T, DP>(Ks, k, b, h, p.D, k0, p.Skv, tid);
+  load_tile<T, DP>(Vs, v, b, h, p.D, k0, p.Skv, tid);
+  float av[DPT], ak[DPT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) av[e] = ak[e] = 0.0f;
-  const float* wrow = ws + (int64_t)(b * H + h) * S * 2;
-  for (int q0 = causal ? k0 : 0; q0 < S; q0 += kT) {
+  for (int e = 0; e < DPT; ++e) av[e] = ak[e] = 0.0f;
+  const float* wrow = ws + (int64_t)(b * p.H + h) * p.Sq * 2;
+  for (int q0 = p.causal ? k0 : 0; q0 < p.Sq; q0 += kT) {
     __syncthreads();
-    load_tile<T>(Qs, q, b, h, q0, S, tid);
-    load_tile<T>(Os, dO, b, h, q0, S, tid);
+    load_tile<T, DP>(Qs, q, b, h, p.D, q0, p.Sq, tid);
+    load_tile<T, DP>(Os, dO, b, h, p.D, q0, p.Sq, tid);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int qi = qg * 4 + t, qq = q0 + qi;
-      const bool ok = qq < S && kk < kmax && (!causal || kk <= qq);
-      float p = 0.0f, ds = 0.0f;
+      const bool ok = qq < p.Sq && kk < kmax && (!p.causal || kk <= qq);
+      float pr = 0.0f, ds = 0.0f;
       if (ok) {
-        const float s = dot128(Qs + qi * kLd, Ks + kj * kLd) * scale;
-        const float dp = dot128(Os + qi * kLd, Vs + kj * kLd);
-        p = __expf(s - wrow[2 * qq]);
-        ds = p * (dp - wrow[2 * qq + 1]);
+        const float s = dot_dp<DP>(Qs + qi * LD, Ks + kj * LD) * p.scale;
+        const float dp = dot_dp<DP>(Os + qi * LD, Vs + kj * LD);
+        pr = __expf(s - wrow[2 * qq]);
+        ds = pr * (dp - wrow[2 * qq + 1]);
       }
-      Ps[qi * 33 + kj] = p;
+      Ps[qi * 33 + kj] = pr;
       Ds[qi * 33 + kj] = ds;
     }
     __syncthreads();
 #pragma unroll 2
     for (int i = 0; i < kT; ++i) {
-      const float p = Ps[i * 33 + kj], ds = Ds[i * 33 + kj];
-      const float* orow = Os + i * kLd + qg * 16;
-      const float* qrow = Qs + i * kLd + qg * 16;
+      const float pr = Ps[i * 33 + kj], ds = Ds[i * 33 + kj];
+      const float* orow = Os + i * LD + qg * DPT;
+      const float* qrow = Qs + i * LD + qg * DPT;
 #pragma unroll
-      for (int e = 0; e < 16; e += 4) {
+      for (int e = 0; e < DPT; e += 4) {
         const float4 x = *reinterpret_cast<const float4*>(orow + e), y = *reinterpret_cast<const float4*>(qrow + e);
-        av[e] = fmaf(p, x.x, av[e]); av[e + 1] = fmaf(p, x.y, av[e + 1]); av[e + 2] = fmaf(p, x.z, av[e + 2]); av[e + 3] = fmaf(p, x.w, av[e + 3]);
+        av[e] = fmaf(pr, x.x, av[e]); av[e + 1] = fmaf(pr, x.y, av[e + 1]); av[e + 2] = fmaf(pr, x.z, av[e + 2]); av[e + 3] = fmaf(pr, x.w, av[e + 3]);
         ak[e] = fmaf(ds, y.x, ak[e]); ak[e + 1] = fmaf(ds, y.y, ak[e + 1]); ak[e + 2] = fmaf(ds, y.z, ak[e + 2]); ak[e + 3] = fmaf(ds, y.w, ak[e + 3]);
       }
     }
   }
-  if (kk < S) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) ak[e] *= scale;
-    const int64_t ok_ = (int64_t)b * dk.bs + (int64_t)kk * dk.rs + (int64_t)h * kD + qg * 16;
-    const int64_t ov_ = (int64_t)b * dv.bs + (int64_t)kk * dv.rs + (int64_t)h * kD + qg * 16;
-    st8<T>(dk.p, ok_, ak);
-    st8<T>(dk.p, ok_ + 8, ak + 8);
-    st8<T>(dv.p, ov_, av);
-    st8<T>(dv.p, ov_ + 8, av + 8);
+  if (kk < p.Skv) {
+    store_dims<T, DP>(dk, b, h, p.D, kk, qg * DPT, ak, p.scale);
+    store_dims<T, DP>(dv, b, h, p.D, kk, qg * DPT, av, 1.0f);
   }
 }
-
 
 // =========================================================================================================================
 // MFMA path (16-bit operands)
@@ -552,41 +535,45 @@ int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr d
   return STLLM_OK;
 }
 
-constexpr int kLdsStats = 2 * kTile * 4;
-constexpr int kLdsDq = (4 * kTile + kT * 33) * 4;
-constexpr int kLdsDkv = (4 * kTile + 2 * kT * 33) * 4;
-
-template <typename T>
-int launch_bwd(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, float scale, int causal,
-               const int32_t* kv_len, hipStream_t st) {
+template <typename T, int DP>
+int launch_bwd(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, const BwdDims& p, hipStream_t st) {
+  constexpr int LD = DP + 4;
+  constexpr int lds_stats = 2 * kT * LD * 4, lds_dq = (4 * kT * LD + kT * 33) * 4, lds_dkv = (4 * kT * LD + 2 * kT * 33) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDq) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsDkv) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv) != hipSuccess) {
       stllm_set_error("stllm_attention_bwd: cannot raise the dynamic LDS limit");
       return STLLM_ERR_HIP;
     }
     attr_set = true;
   }
-  const dim3 grid((S + kT - 1) / kT, H, B), block(256);
-  hipLaunchKernelGGL(attn_bwd_stats_kernel<T>, grid, block, kLdsStats, st, q, k, o, dO, ws, H, S, scale, causal, kv_len);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, grid, block, kLdsDq, st, q, k, v, dO, dq, ws, H, S, scale, causal, kv_len);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, grid, block, kLdsDkv, st, q, k, v, dO, dk, dv, ws, H, S, scale, causal, kv_len);
+  const dim3 gq((p.Sq + kT - 1) / kT, p.H, B), gk((p.Skv + kT - 1) / kT, p.H, B), block(256);
+  hipLaunchKernelGGL((attn_bwd_stats_kernel<T, DP>), gq, block, lds_stats, st, q, k, o, dO, ws, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DP>), gq, block, lds_dq, st, q, k, v, dO, dq, ws, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DP>), gk, block, lds_dkv, st, q, k, v, dO, dk, dv, ws, p);
   return STLLM_OK;
+}
+template <typename T>
+int launch_bwd_dp(int D, Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, const BwdDims& p, hipStream_t st) {
+  if (D <= 64) return launch_bwd<T, 64>(q, k, v, o, dO, dq, dk, dv, ws, B, p, st);
+  if (D <= 96) return launch_bwd<T, 96>(q, k, v, o, dO, dq, dk, dv, ws, B, p, st);
+  return launch_bwd<T, 128>(q, k, v, o, dO, dq, dk, dv, ws, B, p, st);
 }
 
 }  // namespace
 
-extern "C" int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int S) { return (int64_t)B * H * S * 2 * 4; }
+extern "C" int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int Sq) { return (int64_t)B * H * Sq * 2 * 4; }
 
 extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                                    int64_t v_bs, int64_t v_rs, const void* o, int64_t o_bs, int64_t o_rs, const void* dO, int64_t do_bs,
                                    int64_t do_rs, void* dq, int64_t dq_bs, int64_t dq_rs, void* dk, int64_t dk_bs, int64_t dk_rs, void* dv,
-                                   int64_t dv_bs, int64_t dv_rs, int B, int H, int S, int D, float scale, int causal, const int32_t* kv_len,
-                                   void* workspace, int64_t workspace_bytes, void* stream) {
-  STLLM_CHECK_ARG(q && k && v && o && dO && dq && dk && dv && B > 0 && H > 0 && S > 0, "stllm_attention_bwd: bad args");
-  STLLM_CHECK_ARG(D == kD, "stllm_attention_bwd: head_dim %d unsupported (128 only: the Llama heads)", D);
-  STLLM_CHECK_ARG(workspace && workspace_bytes >= stllm_attention_bwd_workspace_bytes(B, H, S), "stllm_attention_bwd: workspace too small");
+                                   int64_t dv_bs, int64_t dv_rs, int B, int H, int Sq, int Skv, int D, float scale, int causal,
+                                   const int32_t* kv_len, void* workspace, int64_t workspace_bytes, void* stream) {
+  STLLM_CHECK_ARG(q && k && v && o && dO && dq && dk && dv && B > 0 && H > 0 && Sq > 0 && Skv > 0, "stllm_attention_bwd: bad args");
+  STLLM_CHECK_ARG(D > 0 && D <= 128 && D % 8 == 0, "stllm_attention_bwd: head_dim %d unsupported (multiples of 8 up to 128)", D);
+  STLLM_CHECK_ARG(!causal || Sq == Skv, "stllm_attention_bwd: causal needs Sq == Skv");
+  STLLM_CHECK_ARG(workspace && workspace_bytes >= stllm_attention_bwd_workspace_bytes(B, H, Sq), "stllm_attention_bwd: workspace too small");
   const int eb = dtype == STLLM_F32 ? 4 : 2;
   const void* ps[8] = {q, k, v, o, dO, dq, dk, dv};
   const int64_t st_[16] = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs};
@@ -597,15 +584,16 @@ extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64
   const MPtr DQ{dq, dq_bs, dq_rs}, DK{dk, dk_bs, dk_rs}, DV{dv, dv_bs, dv_rs};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float* ws = reinterpret_cast<float*>(workspace);
+  const BwdDims dims{H, Sq, Skv, D, scale, causal, kv_len};
   int rc;
   const char* force = getenv("STLLM_ATTN_BWD_VALU");
-  const bool valu = force && force[0] == '1';
+  const bool mfma = !(force && force[0] == '1') && D == kD && Sq == Skv;      // the Llama prefill shape
   switch (dtype) {
-    case STLLM_BF16: rc = valu ? launch_bwd<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s)
-                               : launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
-    case STLLM_F16: rc = valu ? launch_bwd<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s)
-                              : launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
-    case STLLM_F32: rc = launch_bwd<float>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, S, scale, causal, kv_len, s); break;
+    case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, scale, causal, kv_len, s)
+                               : launch_bwd_dp<bf16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
+    case STLLM_F16: rc = mfma ? launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, scale, causal, kv_len, s)
+                              : launch_bwd_dp<f16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
+    case STLLM_F32: rc = launch_bwd_dp<float>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
     default: stllm_set_error("stllm_attention_bwd: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;
   }
   if (rc != STLLM_OK) return rc;

@@ -301,6 +301,29 @@ __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict
   }
 }
 
+// ---- exact-erf GELU on raw pre-activations (training keeps them: the forward's fused GELU epilogue does not) ------------------
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const void* __restrict__ x, int64_t ldx, const void* __restrict__ dy, int64_t lddy,
+                                                   void* __restrict__ out, int64_t ldo, int M, int N) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = N >> 3;
+  if (t >= (int64_t)M * per_row) return;
+  const int row = (int)(t / per_row), j = (int)(t % per_row) * 8;
+  float a[8], g[8];
+  load8<T>(x, (int64_t)row * ldx + j, a);
+  if constexpr (BWD) load8<T>(dy, (int64_t)row * lddy + j, g);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if constexpr (BWD) {
+      const float cdf = 0.5f * (1.0f + erf_as(a[e] * 0.70710678118654752f));
+      a[e] = g[e] * (cdf + a[e] * 0.3989422804014327f * __expf(-0.5f * a[e] * a[e]));
+    } else {
+      a[e] = gelu_erf(a[e]);
+    }
+  }
+  store8<T>(out, (int64_t)row * ldo + j, a);
+}
+
 // ---- small elementwise pieces -------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const void* __restrict__ dy, int64_t lddy, const void* __restrict__ y, int64_t ldy,
@@ -513,6 +536,29 @@ extern "C" int stllm_relu_bwd(int dtype, const void* dy, int64_t lddy, const voi
                        hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), dy, lddy, y, ldy, dx, lddx,
                                           rows, cols));
   STLLM_CHECK_LAUNCH("stllm_relu_bwd");
+  return STLLM_OK;
+}
+
+extern "C" int stllm_gelu(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, int rows, int cols, void* stream) {
+  STLLM_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 8 == 0, "stllm_gelu: bad shape rows=%d cols=%d", rows, cols);
+  STLLM_CHECK_ARG(vec_ok(x, ldx, dtype) && vec_ok(out, ldo, dtype), "stllm_gelu: rows must be 16-byte aligned");
+  const int64_t n = (int64_t)rows * (cols / 8);
+  STLLM_DISPATCH_DTYPE(dtype, "stllm_gelu",
+                       hipLaunchKernelGGL((gelu_kernel<T, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, ldx, (const void*)nullptr,
+                                          (int64_t)0, out, ldo, rows, cols));
+  STLLM_CHECK_LAUNCH("stllm_gelu");
+  return STLLM_OK;
+}
+
+extern "C" int stllm_gelu_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int rows, int cols,
+                              void* stream) {
+  STLLM_CHECK_ARG(x && dy && dx && rows > 0 && cols > 0 && cols % 8 == 0, "stllm_gelu_bwd: bad shape rows=%d cols=%d", rows, cols);
+  STLLM_CHECK_ARG(vec_ok(x, ldx, dtype) && vec_ok(dy, lddy, dtype) && vec_ok(dx, lddx, dtype), "stllm_gelu_bwd: rows must be 16-byte aligned");
+  const int64_t n = (int64_t)rows * (cols / 8);
+  STLLM_DISPATCH_DTYPE(dtype, "stllm_gelu_bwd",
+                       hipLaunchKernelGGL((gelu_kernel<T, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, ldx, dy, lddy, dx, lddx,
+                                          rows, cols));
+  STLLM_CHECK_LAUNCH("stllm_gelu_bwd");
   return STLLM_OK;
 }
 

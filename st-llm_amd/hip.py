@@ -388,7 +388,7 @@ def set_option(key, value):
 # current stream, no fallback.
 TRAIN_EXPORTS = ["stllm_transpose", "stllm_norm_bwd_workspace_bytes", "stllm_rmsnorm_bwd", "stllm_layernorm_bwd", "stllm_swiglu",
                  "stllm_swiglu_bwd", "stllm_rope_bwd", "stllm_attention_bwd_workspace_bytes", "stllm_attention_bwd", "stllm_cross_entropy_bwd", "stllm_scatter_add_rows",
-                 "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
+                 "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_gelu", "stllm_gelu_bwd", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
 
@@ -408,12 +408,14 @@ def _tlib():
         L.stllm_rope_bwd.argtypes = [i, p, i64, p, p, i, i, i, i, p]
         L.stllm_attention_bwd_workspace_bytes.restype = c_int64
         L.stllm_attention_bwd_workspace_bytes.argtypes = [i, i, i]
-        L.stllm_attention_bwd.argtypes = [i] + [p, i64, i64] * 8 + [i, i, i, i, f, i, p, p, i64, p]
+        L.stllm_attention_bwd.argtypes = [i] + [p, i64, i64] * 8 + [i, i, i, i, i, f, i, p, p, i64, p]
         L.stllm_cross_entropy_bwd.argtypes = [i, p, i64, p, f, p, i64, i, i, i, p]
         L.stllm_scatter_add_rows.argtypes = [p, i64, p, p, i64, p, i64, i, i, f, p]
         L.stllm_cosine_rows_bwd.argtypes = [p, i64, p, p, i64, p, f, p, i64, i, i, p]
         L.stllm_colsum.argtypes = [i, p, i64, p, i, i, p, i64, p]
         L.stllm_relu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
+        L.stllm_gelu.argtypes = [i, p, i64, p, i64, i, i, p]
+        L.stllm_gelu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
         L.stllm_bcast_add_t.argtypes = [p, p, i, i, i64, f, p]
         L.stllm_adamw.argtypes = [p, p, p, p, p, i, i64, f, f, f, f, f, i, f, p]
         L.stllm_sumsq.argtypes = [p, i64, p, p]
@@ -498,23 +500,30 @@ def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
     return dqkv
 
 
-def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
-                  d_strides=None):
+def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S=None, D, scale, causal=True, kv_len=None, Sq=None, Skv=None, strides=None,
+                  kv_strides=None, do_strides=None, d_strides=None, dkv_strides=None):
     """Gradients of o = softmax(scale * q k^T + masks) v.  q/k/v/dq/dk/dv: 2-D views of the compute dtype as in `attention`
-    (strides = (batch_stride, row_stride) in elements, shared by q, k, v; d_strides by dq, dk, dv); o, do [B*S, H*D]."""
+    (strides = (batch_stride, row_stride) in elements of q; kv_strides of k and v (default: strides); d_strides of dq; dkv_strides of
+    dk and dv (default: d_strides)); o, do [B*Sq, H*D].  S = Sq = Skv for self-attention."""
     td = q.dtype
+    Sq = S if Sq is None else Sq
+    Skv = S if Skv is None else Skv
 
-    def st(t, given):
-        return given if given is not None else (S * t.stride(0), t.stride(0))
-    s_, ds_, os_ = st(q, strides), st(dq, d_strides), st(do, do_strides)
+    def st(t, n, given):
+        return given if given is not None else (n * t.stride(0), t.stride(0))
+    qs = st(q, Sq, strides)
+    ks = st(k, Skv, kv_strides if kv_strides is not None else (strides if Sq == Skv else None))
+    dqs = st(dq, Sq, d_strides)
+    dks = st(dk, Skv, dkv_strides if dkv_strides is not None else (d_strides if Sq == Skv else None))
+    os_ = st(do, Sq, do_strides)
     if kv_len is not None:
         _req(kv_len, torch.int32, "kv_len")
     a = [dtype_code(td)]
-    for t, ss in ((q, s_), (k, s_), (v, s_), (o, os_), (do, os_), (dq, ds_), (dk, ds_), (dv, ds_)):
+    for t, ss in ((q, qs), (k, ks), (v, ks), (o, os_), (do, os_), (dq, dqs), (dk, dks), (dv, dks)):
         a += [_p(t), ss[0], ss[1]]
-    need = int(_tlib().stllm_attention_bwd_workspace_bytes(B, H, S))
+    need = int(_tlib().stllm_attention_bwd_workspace_bytes(B, H, Sq))
     ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-    _check(_tlib().stllm_attention_bwd(*a, B, H, S, D, scale, int(causal), _p(kv_len), _p(ws), need, _stream()), "stllm_attention_bwd")
+    _check(_tlib().stllm_attention_bwd(*a, B, H, Sq, Skv, D, scale, int(causal), _p(kv_len), _p(ws), need, _stream()), "stllm_attention_bwd")
     return dq, dk, dv
 
 
@@ -564,6 +573,25 @@ def relu_bwd(dy, y):
     M, N = dy.shape
     _check(_tlib().stllm_relu_bwd(dtype_code(dy.dtype), _p(dy), dy.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), M, N, _stream()),
            "stllm_relu_bwd")
+    return out
+
+
+def gelu(x):
+    """exact-erf GELU of raw pre-activations x [M,N] (compute dtype) -> same dtype"""
+    _req(x, None, "x")
+    out = torch.empty_like(x)
+    M, N = x.shape
+    _check(_tlib().stllm_gelu(dtype_code(x.dtype), _p(x), x.stride(0), _p(out), out.stride(0), M, N, _stream()), "stllm_gelu")
+    return out
+
+
+def gelu_bwd(x, dy):
+    """dy * gelu'(x) with x the raw pre-activations"""
+    _req(x, None, "x"); _req(dy, x.dtype, "dy")
+    out = torch.empty_like(x)
+    M, N = x.shape
+    _check(_tlib().stllm_gelu_bwd(dtype_code(x.dtype), _p(x), x.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), M, N, _stream()),
+           "stllm_gelu_bwd")
     return out
 
 

@@ -235,18 +235,25 @@ def rope_bwd(dqkv, cos, sin, *, rope_seq, rope_cols):
     return dqkv
 
 
-def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S, D, scale, causal=True, kv_len=None, strides=None, do_strides=None,
-                  d_strides=None):
-    def heads(t, given):
-        bs, rs = given if given is not None else (S * t.stride(0), t.stride(0))
-        return torch.as_strided(t, (B, S, H, D), (bs, rs, D, 1), t.storage_offset())
-    qh, kh, vh = (heads(t, strides).float().transpose(1, 2) for t in (q, k, v))
-    doh = heads(do, do_strides).float().transpose(1, 2)
+def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S=None, D, scale, causal=True, kv_len=None, Sq=None, Skv=None, strides=None,
+                  kv_strides=None, do_strides=None, d_strides=None, dkv_strides=None):
+    Sq = S if Sq is None else Sq
+    Skv = S if Skv is None else Skv
+
+    def heads(t, n, given):
+        bs, rs = given if given is not None else (n * t.stride(0), t.stride(0))
+        return torch.as_strided(t, (B, n, H, D), (bs, rs, D, 1), t.storage_offset())
+    same = Sq == Skv
+    ks = kv_strides if kv_strides is not None else (strides if same else None)
+    dks = dkv_strides if dkv_strides is not None else (d_strides if same else None)
+    qh = heads(q, Sq, strides).float().transpose(1, 2)
+    kh, vh = (heads(t, Skv, ks).float().transpose(1, 2) for t in (k, v))
+    doh = heads(do, Sq, do_strides).float().transpose(1, 2)
     s = (qh @ kh.transpose(-1, -2)) * scale
     if causal:
-        s = s.masked_fill(torch.ones(S, S).triu(1).bool(), float("-inf"))
+        s = s.masked_fill(torch.ones(Sq, Skv).triu(1).bool(), float("-inf"))
     if kv_len is not None:
-        dead = torch.arange(S)[None, :] >= kv_len.long()[:, None]
+        dead = torch.arange(Skv)[None, :] >= kv_len.long()[:, None]
         s = s.masked_fill(dead[:, None, None, :], float("-inf"))
     p = s.softmax(-1)
     gv = p.transpose(-1, -2) @ doh
@@ -254,8 +261,9 @@ def attention_bwd(q, k, v, o, do, dq, dk, dv, *, B, H, S, D, scale, causal=True,
     ds = p * (dp - (dp * p).sum(-1, keepdim=True))
     gq = (ds @ kh) * scale
     gk = (ds.transpose(-1, -2) @ qh) * scale
-    for dst, val in ((dq, gq), (dk, gk), (dv, gv)):
-        heads(dst, d_strides).copy_(val.transpose(1, 2).to(dst.dtype))
+    heads(dq, Sq, d_strides).copy_(gq.transpose(1, 2).to(dq.dtype))
+    heads(dk, Skv, dks).copy_(gk.transpose(1, 2).to(dk.dtype))
+    heads(dv, Skv, dks).copy_(gv.transpose(1, 2).to(dv.dtype))
     return dq, dk, dv
 
 
@@ -298,6 +306,17 @@ def relu_bwd(dy, y):
     return dy * (y > 0).to(dy.dtype)
 
 
+def gelu(x):
+    xf = x.float()
+    return (0.5 * xf * (1.0 + torch.erf(xf / math.sqrt(2.0)))).to(x.dtype)
+
+
+def gelu_bwd(x, dy):
+    xf = x.float()
+    cdf = 0.5 * (1.0 + torch.erf(xf / math.sqrt(2.0)))
+    return (dy.float() * (cdf + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2.0 * math.pi))).to(x.dtype)
+
+
 def bcast_add_t(dst, src, scale):
     dst += scale * src.unsqueeze(1)
 
@@ -327,7 +346,7 @@ def installed():
     names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
              "cross_entropy_rows", "cast_rows", "preprocess_frames", "transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu",
              "swiglu_bwd", "rope_bwd", "attention_bwd", "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum",
-             "relu_bwd", "bcast_add_t", "adamw", "sumsq"]
+             "relu_bwd", "gelu", "gelu_bwd", "bcast_add_t", "adamw", "sumsq"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

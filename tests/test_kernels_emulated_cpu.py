@@ -328,3 +328,40 @@ def test_emulated_forward_elementwise():
     close(cs, C.cosine_rows(a, bsrc, None, torch.tensor([4, 0, 1, 1, 2, 3], dtype=torch.int32), n_rows=6), 1e-5, "cosine_rows")
     close(ce, C.cross_entropy_rows(logits, labels), 1e-5, "cross_entropy_rows")
     assert torch.equal(c16, a.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gelu_and_backward(dtype):
+    x, dy = rnd(7, 72, seed=70, dtype=dtype, scale=2.0), rnd(7, 72, seed=71, dtype=dtype)
+    with _hipemu.emulated() as hip:
+        y, dx = hip.gelu(x), hip.gelu_bwd(x, dy)
+    close(y, C.gelu(x), TOL[dtype] if dtype != torch.float32 else 2e-6, "gelu")
+    close(dx, C.gelu_bwd(x, dy), TOL[dtype] if dtype != torch.float32 else 2e-6, "gelu_bwd")
+    xv = x.float().clone().requires_grad_(True)
+    with torch.enable_grad():
+        torch.nn.functional.gelu(xv).backward(dy.float())
+    close(C.gelu_bwd(x.float(), dy.float()), xv.grad, 1e-6, "contract vs autograd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [dict(B=2, H=2, Sq=44, Skv=44, D=64, lens=[44, 37]),      # Q-Former self-attention [queries | text], key mask
+                                   dict(B=2, H=2, Sq=32, Skv=70, D=64, lens=None),          # Q-Former cross-attention, Sq != Skv
+                                   dict(B=1, H=2, Sq=70, Skv=70, D=88, lens=None)])         # EVA / BT-Adapter heads: 88 padded to 96 in LDS
+def test_attention_bwd_general_heads(dtype, shape):
+    B, H, Sq, Skv, D = shape["B"], shape["H"], shape["Sq"], shape["Skv"], shape["D"]
+    HD = H * D
+    q = rnd(B * Sq, HD, seed=72, dtype=dtype, scale=0.7)
+    kv = rnd(B * Skv, 2 * HD, seed=73, dtype=dtype, scale=0.7)
+    do = rnd(B * Sq, HD, seed=74, dtype=dtype)
+    k, v = kv[:, :HD], kv[:, HD:]
+    kv_len = None if shape["lens"] is None else torch.tensor(shape["lens"], dtype=torch.int32)
+    o = C.attention(q, k, v, B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=D ** -0.5, kv_len=kv_len)
+    wq, wkv = torch.zeros_like(q), torch.zeros_like(kv)
+    C.attention_bwd(q, k, v, o, do, wq, wkv[:, :HD], wkv[:, HD:], B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=D ** -0.5, causal=False, kv_len=kv_len)
+    gq, gkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    with _hipemu.emulated() as hip:
+        hip.attention_bwd(q, k, v, o, do, gq, gkv[:, :HD], gkv[:, HD:], B=B, H=H, Sq=Sq, Skv=Skv, D=D, scale=D ** -0.5, causal=False,
+                          kv_len=kv_len)
+    tol = 2e-5 if dtype == torch.float32 else 2 * TOL[dtype]
+    close(gq, wq, tol, "dq")
+    close(gkv, wkv, tol, "dk|dv")
