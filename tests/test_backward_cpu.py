@@ -165,3 +165,35 @@ def test_btadapter_backbone_with_frozen_adapter():
     assert set(grads) == set(want) == {n for n, _ in training.trainable_parameters(model)}
     for n, gr in grads.items():
         assert (gr - want[n]).abs().max().item() <= 3e-4 * want[n].abs().max().item(), n
+
+
+@pytest.mark.parametrize("text", [False, True])
+def test_qformer_backward_to_image_tokens(text):
+    """training_vision.qformer_backward: the dgrad-only sweep through the frozen Q-Former (2 layers: one with cross-attention, one
+    without; with and without the text stream and its key mask) against autograd over the oracle's qformer_forward."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build
+    from stllm_amd import runtime, training_vision
+    cfg = CFGS["instructblip_residual_text" if text else "mean_pooling"]
+    model = build(cfg, vit_depth=1, qf_layers=2, llm_layers=1)
+    sm = model.model.stllm_model
+    sd = sd_from(shapes.stllm_model_shapes(1, 2, text, cfg["video_input"], False, qf_vocab=32000))
+    p = "model.stllm_model."
+    n, P = 3, 257
+    enc = T("input.qf_enc", (n, P, 1408), 0.7)
+    R = T("input.qf_dout", (n, 32, 768), 1.0)
+    ids = mask = att = None
+    if text:
+        ids = torch.tensor([[1, 17, 23, 9, 4], [1, 8, 0, 0, 0], [1, 5, 6, 7, 0]])
+        mask = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 0, 0, 0], [1, 1, 1, 1, 0]])
+        att = torch.cat([torch.ones(n, 32, dtype=torch.long), mask], dim=1)
+    ev = enc.clone().requires_grad_(True)
+    with torch.enable_grad():
+        out = O.qformer_forward(sd[p + "query_tokens"].expand(n, -1, -1), ev, sd, p + "Qformer.bert.", ids, att)[:, :32]
+        (out * R).sum().backward()
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        hq32, _, tape = training_vision.qformer_forward_taped(sm.Qformer.bert, sm.query_tokens[0], enc.reshape(n * P, 1408).clone(), n, ids, mask)
+        d_enc = training_vision.qformer_backward(sm.Qformer.bert, tape, R.reshape(n * 32, 768))
+    assert (hq32.view(n, 32, 768) - out.detach()).abs().max() <= 2e-5 * out.abs().max()
+    want = ev.grad.reshape(n * P, 1408)
+    assert (d_enc - want).abs().max().item() <= 3e-4 * want.abs().max().item()
