@@ -158,3 +158,153 @@ def qformer_backward(bert, tape, d_hq32):
         if Lt:
             _dgrad(d_qkv[Q:], pk["wqkv"], dt, epilogue=hip.EPI_RESID, resid=d_ht, M=n * Lt, a_rows=(Lt, S * 3 * C))
     return d_enc
+
+
+# =========================================================================================================================
+# BT-Adapter (eva_btadapter.py:147-310): forward that keeps the branch's activations, and the branch's backward.
+# The frozen ViT stream `h` is a constant input of the branch at every adapter layer (the backbone never reads the branch), so
+# only the side branch is differentiated: 3 x (temporal block over T per patch, spatial block over the 257 tokens per frame).
+# =========================================================================================================================
+from .training import linear_bwd   # noqa: E402  (dgrad + wgrad of y = x @ w^T through stllm_gemm on transposed operands)
+
+
+def btadapter_forward_taped(vit, x):
+    """EVAVisionTransformer_BTAdapter.forward_flat (models/eva_btadapter.py) keeping what the branch's backward needs.
+    Returns (flat fp32 stream [(B*T)*257, 1408], tape)."""
+    from .models.eva_vit import block_forward
+    if x.ndim == 5:
+        if x.shape[1] == 3:
+            x = x.permute(0, 2, 1, 3, 4)
+        B, T = x.shape[0], x.shape[1]
+        x = x.reshape((-1,) + tuple(x.shape[2:]))
+    elif x.ndim == 4:
+        T, B = x.shape[0], 1
+    else:
+        raise ValueError("expected 4-D or 5-D input")
+    vit.T = T
+    dt = runtime.compute_dtype()
+    pk, bt = vit.pack(dt), vit.pack_bt(dt)
+    dev = x.device
+    tb = vit._tables(B, T, dev)
+    P, L, D, H = tb["P"], tb["L"], vit.embed_dim, vit.num_heads
+    N, nbr = B * T, B * tb["P"] * T
+    hd = D // H
+    h = vit.embed_flat(x, pk, dt)
+    br = None
+    tape = dict(B=B, T=T, layers=[], tb=tb)
+    for i, bp_ in enumerate(pk["blocks"]):
+        block_forward(h, bp_, N, L, H, dt)
+        if i < vit.num_layers - vit.depth:
+            continue
+        j = i + vit.depth - vit.num_layers
+        rec = {}
+        new = torch.empty((nbr + B, D), device=dev, dtype=torch.float32)
+        cls_mean = vit._cls_mean(h, tb["cls_main"], B, T)
+        if br is None:
+            pt = hip.gather_rows(pk["pos"], (1 + torch.arange(P).view(P, 1).expand(P, T)).reshape(-1).to(torch.int32).to(dev),
+                                 add=vit.BTAdapter_position.weight,
+                                 idx_add=torch.arange(T).view(1, T).expand(P, T).reshape(-1).to(torch.int32).to(dev))
+            hip.gather_rows(h, tb["main_of_bpt"], add=pt, idx_add=tb["pt_of_bpt"], out=new[:nbr])
+            cls_br = hip.gather_rows(vit.BTAdapter_cls.view(1, D).float().contiguous(), tb["zeros_b"][:1], add=pk["pos"],
+                                     idx_add=tb["zeros_b"][:1])
+            hip.gather_rows(cls_mean, tb["arange_b"], add=cls_br, idx_add=tb["zeros_b"], out=new[nbr:], scale=0.5)
+        else:
+            hip.gather_rows(h, tb["main_of_bpt"], add=br, idx_add=tb["arange_bpt"], out=new[:nbr])
+            hip.gather_rows(cls_mean, tb["arange_b"], add=br[nbr:], idx_add=tb["arange_b"], out=new[nbr:])
+        br = new
+        # ---- temporal block ----
+        t_ = bt["T"][j]
+        patches = br[:nbr]
+        rec["t_in"] = patches.clone()
+        rec["t_hn"], _ = hip.layernorm(patches, t_["n1w"], t_["n1b"], t_["e1"], dtype=dt)
+        rec["t_qkv"] = hip.gemm(rec["t_hn"], t_["wqkv"], dtype=dt, bias=t_["bqkv"])
+        q = rec["t_qkv"]
+        rec["t_a"] = hip.attention(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], B=B * P, H=H, Sq=T, Skv=T, D=hd, scale=hd ** -0.5)
+        rec["t_pr"] = hip.gemm(rec["t_a"], t_["wproj"], dtype=dt, bias=t_["bproj"])
+        hip.gemm(rec["t_pr"], t_["wfc"], dtype=dt, epilogue=hip.EPI_RESID, bias=t_["bfc"], resid=patches)
+        # ---- spatial block ----
+        s_ = bt["S"][j]
+        rec["s_x"] = hip.gather_rows(br, tb["sp_src"])
+        rec["s_hn1"], _ = hip.layernorm(rec["s_x"], s_["n1w"], s_["n1b"], s_["e1"], dtype=dt)
+        rec["s_qkv"] = hip.gemm(rec["s_hn1"], s_["wqkv"], dtype=dt, bias=s_["bqkv"])
+        q = rec["s_qkv"]
+        rec["s_a"] = hip.attention(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], B=N, H=H, Sq=L, Skv=L, D=hd, scale=hd ** -0.5)
+        res = hip.gemm(rec["s_a"], s_["wproj"], dtype=dt, bias=s_["bproj"], out_f32=True)
+        nxt = torch.empty_like(br)
+        hip.gather_rows(res, tb["sp_patch_rows"], add=br, idx_add=tb["arange_bpt"], out=nxt[:nbr])
+        cls_res = vit._cls_mean(res, tb["sp_cls_rows"], B, T)
+        hip.gather_rows(cls_res, tb["arange_b"], add=br[nbr:], idx_add=tb["arange_b"], out=nxt[nbr:])
+        br = nxt
+        rec["m_in"] = br.clone()
+        rec["m_hn"], _ = hip.layernorm(br, s_["n2w"], s_["n2b"], s_["e2"], dtype=dt)
+        rec["m_raw"] = hip.gemm(rec["m_hn"], s_["wfc1"], dtype=dt, bias=s_["bfc1"])
+        rec["m_g"] = hip.gelu(rec["m_raw"])
+        hip.gemm(rec["m_g"], s_["wfc2"], dtype=dt, epilogue=hip.EPI_RESID, bias=s_["bfc2"], resid=br)
+        tape["layers"].append(rec)
+    out = hip.gather_rows(br, tb["out_src"], add=h, idx_add=tb["arange_main"], scale=0.5)
+    return out, tape
+
+
+def _attn_block_bwd(grads, name, d_out16, a, qkv, hn, pk_w, pk_proj, Bn, H, S, D, dt):
+    """y = proj(attention(hn @ Wqkv^T + [q_bias, 0, v_bias])): weight / bias gradients into `grads`, returns d(hn) (compute dtype)"""
+    hd = D // H
+    d_a, dw = linear_bwd(d_out16, a, pk_proj, dt)
+    grads[name + "attn.proj.weight"], grads[name + "attn.proj.bias"] = dw, hip.colsum(d_out16)
+    d_qkv = torch.empty_like(qkv)
+    hip.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, d_a, d_qkv[:, :D], d_qkv[:, D:2 * D], d_qkv[:, 2 * D:], B=Bn, H=H, S=S,
+                      D=hd, scale=hd ** -0.5, causal=False)
+    d_hn, dw = linear_bwd(d_qkv, hn, pk_w, dt)
+    bsum = hip.colsum(d_qkv)
+    grads[name + "attn.qkv.weight"] = dw
+    grads[name + "attn.q_bias"], grads[name + "attn.v_bias"] = bsum[:D].clone(), bsum[2 * D:].clone()
+    return d_hn
+
+
+def btadapter_backward(vit, tape, d_out, prefix="model.stllm_model.visual_encoder."):
+    """d_out: gradient w.r.t. forward_flat's output, f32 [(B*T)*257, D].  Returns {reference name: fp32 gradient} of every
+    `BTAdapter*` parameter."""
+    dt = runtime.compute_dtype()
+    bt = vit.pack_bt(dt)
+    tb, B, T = tape["tb"], tape["B"], tape["T"]
+    P, L, D, H = tb["P"], tb["L"], vit.embed_dim, vit.num_heads
+    N, nbr = B * T, B * P * T
+    dev = d_out.device
+    grads = {}
+    d_br = torch.zeros((nbr + B, D), device=dev, dtype=torch.float32)
+    hip.scatter_add_rows(d_out, tb["out_src"], d_br, scale=0.5)                    # out = (br[out_src] + h) / 2
+    for j in range(vit.depth - 1, -1, -1):
+        rec, s_, t_ = tape["layers"][j], bt["S"][j], bt["T"][j]
+        sp, tp = f"{prefix}BTAdapter_S.{j}.", f"{prefix}BTAdapter_T.{j}."
+        # ---- MLP: br += fc2(gelu(fc1(LN2(br)))) -----------------------------------------------------------------------------
+        d16 = hip.cast_rows(d_br, dt)
+        d_g, dw = linear_bwd(d16, rec["m_g"], s_["wfc2"], dt)
+        grads[sp + "mlp.fc2.weight"], grads[sp + "mlp.fc2.bias"] = dw, hip.colsum(d16)
+        d_raw = hip.gelu_bwd(rec["m_raw"], d_g)
+        d_hn, dw = linear_bwd(d_raw, rec["m_hn"], s_["wfc1"], dt)
+        grads[sp + "mlp.fc1.weight"], grads[sp + "mlp.fc1.bias"] = dw, hip.colsum(d_raw)
+        _, grads[sp + "norm2.weight"], grads[sp + "norm2.bias"] = hip.layernorm_bwd(rec["m_in"], s_["n2w"], s_["e2"], d_hn, d_br, accumulate=True)
+        # ---- spatial attention: nxt = res[patch rows] + br ; CLS: mean_t(res[cls rows]) + br --------------------------------------
+        d_res = torch.zeros((N * L, D), device=dev, dtype=torch.float32)
+        hip.scatter_add_rows(d_br, tb["sp_patch_rows"], d_res)                     # rows [:nbr] of d_br
+        d_cls = torch.zeros((B, T, D), device=dev, dtype=torch.float32)
+        hip.bcast_add_t(d_cls, d_br[nbr:].contiguous(), 1.0 / T)
+        hip.scatter_add_rows(d_cls.view(B * T, D), tb["sp_cls_rows"], d_res)
+        d_res16 = hip.cast_rows(d_res, dt)
+        d_hn = _attn_block_bwd(grads, sp, d_res16, rec["s_a"], rec["s_qkv"], rec["s_hn1"], s_["wqkv"], s_["wproj"], N, H, L, D, dt)
+        d_sx, grads[sp + "norm1.weight"], grads[sp + "norm1.bias"] = hip.layernorm_bwd(rec["s_x"], s_["n1w"], s_["e1"], d_hn)
+        hip.scatter_add_rows(d_sx, tb["sp_src"], d_br)                             # sx = br[sp_src]
+        # ---- temporal block on the patch rows: p += fc(proj(attention(LN(p)))) --------------------------------------------------
+        d_p = d_br[:nbr]
+        d_p16 = hip.cast_rows(d_p, dt)
+        d_pr, dw = linear_bwd(d_p16, rec["t_pr"], t_["wfc"], dt)
+        grads[tp + "temporal_fc.weight"], grads[tp + "temporal_fc.bias"] = dw, hip.colsum(d_p16)
+        d_hn = _attn_block_bwd(grads, tp, d_pr, rec["t_a"], rec["t_qkv"], rec["t_hn"], t_["wqkv"], t_["wproj"], B * P, H, T, D, dt)
+        _, grads[tp + "norm1.weight"], grads[tp + "norm1.bias"] = hip.layernorm_bwd(rec["t_in"], t_["n1w"], t_["e1"], d_hn, d_p, accumulate=True)
+        # ---- layer input: j > 0: new = gather(h) + previous branch (identity);  j == 0: init_input ------------------------------------
+    d_pt = torch.zeros((P * T, D), device=dev, dtype=torch.float32)
+    hip.scatter_add_rows(d_br, tb["pt_of_bpt"], d_pt)                              # new[:nbr] = h[...] + (pos[1+p] + position[t])[p*T+t]
+    d_pos = torch.zeros_like(vit.BTAdapter_position.weight, dtype=torch.float32)
+    hip.scatter_add_rows(d_pt, torch.arange(T).view(1, T).expand(P, T).reshape(-1).to(torch.int32).to(dev), d_pos)
+    grads[prefix + "BTAdapter_position.weight"] = d_pos
+    grads[prefix + "BTAdapter_cls"] = (hip.colsum(d_br[nbr:].contiguous()) * 0.5).view(1, 1, D)   # new[nbr:] = (cls_mean + cls + pos[0]) / 2
+    return grads

@@ -197,3 +197,34 @@ def test_qformer_backward_to_image_tokens(text):
     assert (hq32.view(n, 32, 768) - out.detach()).abs().max() <= 2e-5 * out.abs().max()
     want = ev.grad.reshape(n * P, 1408)
     assert (d_enc - want).abs().max().item() <= 3e-4 * want.abs().max().item()
+
+
+def test_btadapter_branch_backward():
+    """training_vision.btadapter_backward: gradients of every BTAdapter* parameter (3 temporal + 3 spatial blocks, BTAdapter_cls,
+    BTAdapter_position) for a random output gradient, against autograd over the oracle's btadapter_forward (4-block ViT)."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build
+    from stllm_amd import runtime, training_vision
+    cfg = CFGS["btadapter"]
+    model = build(cfg, vit_depth=4, qf_layers=2, llm_layers=1)
+    vit = model.model.stllm_model.visual_encoder
+    p = "model.stllm_model.visual_encoder."
+    sd = sd_from(shapes.stllm_model_shapes(4, 2, False, cfg["video_input"], False, vit_model=cfg["vit_model"], qf_vocab=32000))
+    x = T("input.video", (2, 3, 3, 224, 224))[:, :, :, :, :]            # B = 2 clips x T = 3 frames
+    x = torch.cat([x, x.flip(1)[:, :1]], dim=1)                         # T = 4 (not a [B,3,...] layout)
+    names = [n for n in sd if n.startswith(p) and "BTAdapter" in n]
+    for n in names:
+        sd[n].requires_grad_(True)
+    R = T("input.bt_dout", (2 * 4 * 257, 1408), 1.0)
+    with torch.enable_grad():
+        out = O.btadapter_forward(x, sd, p, 3).reshape(-1, 1408)
+        (out * R).sum().backward()
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        got_out, tape = training_vision.btadapter_forward_taped(vit, x)
+        grads = training_vision.btadapter_backward(vit, tape, R)
+    assert (got_out - out.detach()).abs().max() <= 3e-5 * out.abs().max()
+    assert set(grads) == set(names), set(grads) ^ set(names)
+    for n in names:
+        want = sd[n].grad
+        assert grads[n].shape == want.shape, n
+        assert (grads[n] - want).abs().max().item() <= 3e-4 * want.abs().max().item(), n
