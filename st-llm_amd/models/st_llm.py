@@ -136,18 +136,27 @@ class STLLMModel(Blip2Base):
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
             atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
             return inputs_llama, atts_llama, use_image
+        taped_vision = self._tape is not None and self._tape.get("want_vision", False) and self.vit_model != "eva_clip_g"
         if self.vit_model == "eva_clip_g":
             frames = image.reshape((-1,) + tuple(image.shape[2:])) if image.dim() == 5 else image
             feats = self.visual_encoder.forward_features_flat(frames)
             n = frames.shape[0]
         else:
-            feats = self.visual_encoder.forward_flat(image)
+            if taped_vision:   # training of the BTAdapter* parameters: keep the branch's activations (training_vision.py)
+                from .. import training_vision
+                feats, self._tape["bt_tape"] = training_vision.btadapter_forward_taped(self.visual_encoder, image)
+            else:
+                feats = self.visual_encoder.forward_flat(image)
             n = feats.shape[0] // 257
         enc16, _ = hip.layernorm(feats, self.ln_vision.weight, self.ln_vision.bias, self.ln_vision.eps, dtype=dt)
         ids = tmask = None
         if self.qformer_text_input:
             ids, tmask = self._qformer_ids(text, n, T)
-        _, hq16, _ = self.Qformer.bert.encode(self.query_tokens[0], enc16, n, ids, tmask)
+        if taped_vision:       # ... and the frozen Q-Former's, for the dgrad sweep back to the image tokens
+            _, hq16, self._tape["qf_tape"] = training_vision.qformer_forward_taped(self.Qformer.bert, self.query_tokens[0], enc16, n, ids, tmask)
+            self._tape["feats"] = feats
+        else:
+            _, hq16, _ = self.Qformer.bert.encode(self.query_tokens[0], enc16, n, ids, tmask)
         if self._tape is not None:
             self._tape["hq16"] = hq16
         w, b = self.llama_proj.packed(dt)

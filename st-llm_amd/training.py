@@ -19,9 +19,9 @@ MI355X-first choices:
     needs no recomputation of the largest GEMM;
   * q/k gradients are rotated back by `stllm_rope_bwd` in the packed head layout, weight gradients are produced in the packed
     layouts of pack.py and un-permuted once per step into the reference's parameter layout (index permutations only).
-BT-Adapter parameters (model_type *_btadapter — 4 of the 5 shipped training configs) are not differentiated yet: their gradient
-needs the backward through the frozen Q-Former.  `loss_and_grads(..., freeze_btadapter=True)` trains everything else on that
-backbone with the adapter frozen; without the flag it raises.
+BT-Adapter parameters (model_type *_btadapter — 4 of the 5 shipped training configs): their gradient goes back through llama_proj,
+the frozen Q-Former and ln_vision into the adapter branch (training_vision.py).  The reference's stochastic depth in the adapter
+blocks (drop_path 0.1 in train mode, eva_btadapter.py:260) is not applied: the step is the deterministic (eval-mode) one.
 
 Layout of the result: {reference parameter name: fp32 gradient in the reference's layout}.
 """
@@ -178,20 +178,19 @@ def _acc(grads, name, g):
 
 def loss_and_grads(model, samples, freeze_btadapter=False):
     """model: STLLMForCausalLM.  Returns (loss fp32 scalar tensor, loss_mvm or None, grads {reference name: fp32 tensor}).
-    freeze_btadapter: accept the eva_btadapter_g backbone with its adapter treated as frozen (the reference trains the `BTAdapter*`
-    parameters too, st_llm.py:257-261; their gradient needs the backward THROUGH the frozen Q-Former, which is not built yet)."""
+    On the eva_btadapter_g backbone the reference also trains the `visual_encoder.BTAdapter*` parameters (st_llm.py:257-261): their
+    gradient is carried back through llama_proj, the frozen Q-Former and ln_vision into the adapter branch (training_vision.py);
+    freeze_btadapter=True skips that and treats the adapter as frozen."""
     lmw = model                                  # lm_head owner
     lm = model.model                             # STLLMLlamaModel (LlamaModel + stllm_model)
     sm = lm.stllm_model
-    if sm.vit_model != "eva_clip_g" and not freeze_btadapter:
-        raise NotImplementedError("BT-Adapter parameters are not differentiated yet (SURVEY.md §8f rank 3, adapter part): pass "
-                                  "freeze_btadapter=True to train everything else with the adapter frozen")
+    train_adapter = sm.vit_model != "eva_clip_g" and not freeze_btadapter
     if sm.frame_parallel is not None:
         raise NotImplementedError("training is data-parallel (one micro-batch per rank); frame-parallel is the inference path")
     dt = runtime.compute_dtype()
     cfg = lm.config
     D = cfg.hidden_size
-    sm._tape = tape = {}
+    sm._tape = tape = {"want_vision": train_adapter}
     try:
         inputs_embeds, attention_mask, un_e, un_a, labels = sm(samples)
     finally:
@@ -292,20 +291,27 @@ def loss_and_grads(model, samples, freeze_btadapter=False):
     # ---- projector (st_llm.py:368): inputs_llama = hq @ W^T + b; the Q-Former below it is frozen ---------------------------
     w, _ = sm.llama_proj.packed(dt)
     d_tok16 = hip.cast_rows(d_tok, dt)
-    _, dw = linear_bwd(d_tok16, tape["hq16"], w, dt, need_dx=False)
+    d_hq, dw = linear_bwd(d_tok16, tape["hq16"], w, dt, need_dx=train_adapter, dx_f32=True)
     grads[p + "llama_proj.weight"], grads[p + "llama_proj.bias"] = dw, hip.colsum(d_tok16)
+    # ---- BT-Adapter: back through the frozen Q-Former and ln_vision into the adapter branch (training_vision.py) ------------------
+    if train_adapter:
+        from . import training_vision
+        d_enc = training_vision.qformer_backward(sm.Qformer.bert, tape["qf_tape"], d_hq)
+        d_feats, _, _ = hip.layernorm_bwd(tape["feats"], sm.ln_vision.weight, sm.ln_vision.eps, d_enc)
+        grads.update(training_vision.btadapter_backward(sm.visual_encoder, tape["bt_tape"], d_feats, p + "visual_encoder."))
     return loss, loss_mvm, grads
 
 
 # ---- optimizer --------------------------------------------------------------------------------------------------------
-def trainable_parameters(model):
-    """(name, parameter) of what the reference leaves trainable (st_llm.py:182-186, 257-296 with the shipped configs) — minus the
-    `visual_encoder.BTAdapter*` parameters of the eva_btadapter_g backbone, which `loss_and_grads` does not differentiate yet."""
+def trainable_parameters(model, freeze_btadapter=False):
+    """(name, parameter) of what the reference leaves trainable (st_llm.py:182-186, 257-296 with the shipped configs): everything
+    but the ViT, ln_vision, the Q-Former and its query tokens — the `BTAdapter*` parameters inside visual_encoder stay trainable
+    (st_llm.py:259) unless freeze_btadapter."""
     frozen = ("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
               "model.stllm_model.query_tokens")
     seen = set()
     for n, prm in model.named_parameters():
-        if n.startswith(frozen) or id(prm) in seen:
+        if (n.startswith(frozen) and ("BTAdapter" not in n or freeze_btadapter)) or id(prm) in seen:
             continue
         seen.add(id(prm))
         yield n, prm
@@ -430,3 +436,5 @@ def invalidate_packed(model):
             getattr(sm, name)._packed = {}
     if hasattr(sm, "mvm_decoder"):
         sm.mvm_decoder.head._packed = {}
+    if hasattr(sm.visual_encoder, "_bt_packed"):
+        sm.visual_encoder._bt_packed = {}
