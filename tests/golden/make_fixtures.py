@@ -402,11 +402,21 @@ def fx_backward():
         "residual": (dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="",
                           video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
                           qformer_text_input=True, max_txt_len=32, end_sym=" 2", vit_precision="fp32"), 8),
+        # the backbone of 4 of the 5 shipped training configs: visual_encoder.BTAdapter* stay trainable (st_llm.py:257-261)
+        "btadapter": (dict(vit_model="eva_btadapter_g", image_size=224, num_query_token=32, llama_model="", video_input="all",
+                           use_mask=False, mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2",
+                           vit_precision="fp32"), 4),
     }
+    depths = {"btadapter": (4, 2, 1)}                      # (ViT blocks, Q-Former layers, Llama layers); default (1, 2, 2)
+    only = os.environ.get("STLLM_FX_BACKWARD_ONLY")        # regenerate one case, keep the others
     arrs = {}
+    if only:
+        old = np.load(os.path.join(HERE, "backward.npz"))
+        arrs = {k: old[k] for k in old.files if not k.startswith(only + ".")}
+        cases = {only: cases[only]}
     for tag, (cfg, Tn) in cases.items():
         cfg = _Cfg(cfg)
-        model = fill_stllm(_build_ref_stllm(cfg, 1, 2, 2))
+        model = fill_stllm(_build_ref_stllm(cfg, *depths.get(tag, (1, 2, 2))))
         samples, meta = _samples(2, Tn, cfg.get("qformer_text_input", False))
         np.random.seed(1234)
         with torch.enable_grad():
@@ -423,7 +433,7 @@ def fx_backward():
             arrs[f"{tag}.slice.{n}"] = sub(g, 97, 101) if g.dim() == 2 else sub(g, 29)
         frozen = [n for n, prm in model.named_parameters() if prm.grad is None]
         assert all(n.startswith(("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
-                                 "model.stllm_model.query_tokens")) for n in frozen), frozen[:5]
+                                 "model.stllm_model.query_tokens")) and "BTAdapter" not in n for n in frozen), frozen[:5]
         arrs[f"{tag}.names"] = np.array(names)
         arrs[f"{tag}.loss"] = np.array([out.loss.item()])
         text = cfg.get("qformer_text_input", False)       # effective id streams, as in fx_stllm

@@ -18,6 +18,7 @@ CASES = {
     "residual": (dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
                       qformer_text_input=True), 8),
 }
+BT_CASE = dict(vit_model="eva_btadapter_g", video_input="all", use_mask=False, mvm_decode=False, qformer_text_input=False)
 FROZEN = ("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
           "model.stllm_model.query_tokens")
 
@@ -144,31 +145,27 @@ def test_mean_pooling_backward_and_one_optimizer_step():
     assert l1.item() < l0.item() - 0.05, (l0.item(), l1.item())
 
 
-def test_btadapter_backbone_end_to_end():
+def test_btadapter_backbone_end_to_end_matches_reference():
     """eva_btadapter_g backbone (4 of the 5 shipped training configs): loss_and_grads carries the gradient through llama_proj, the
-    frozen Q-Former and ln_vision into the adapter branch; every trainable tensor (LLM, projector, BTAdapter*) matches autograd
-    over the oracle.  freeze_btadapter=True drops exactly the adapter's entries."""
+    frozen Q-Former and ln_vision into the adapter branch; every trainable tensor (LLM, projector, all BTAdapter*) matches the
+    REFERENCE's own loss.backward() (tests/golden/backward.npz, case "btadapter": 4 ViT blocks, 3 adapter layers, 1 Llama layer).
+    freeze_btadapter=True names exactly the non-adapter entries."""
     import _cpu_backend
-    from test_host_orchestration_cpu import CFGS, build, make_inputs
+    from test_host_orchestration_cpu import build
     from stllm_amd import runtime, training
-    cfg = CFGS["btadapter"]
-    model = build(cfg, vit_depth=4, qf_layers=2, llm_layers=1)
-    samples, osamples = make_inputs(2, 4, False)
-    sd = sd_from({**shapes.stllm_model_shapes(4, 2, False, cfg["video_input"], cfg["mvm_decode"], vit_model=cfg["vit_model"], qf_vocab=32000),
-                  **shapes.llama_shapes(1)})
-    want_loss, want = oracle_grads(cfg, sd, osamples)
+    g = golden("backward")
+    model = build(dict(BT_CASE, image_size=224, num_query_token=32, max_txt_len=32, end_sym=" 2"), vit_depth=4, qf_layers=2, llm_layers=1)
+    instr, answers = product_samples(g, "btadapter", False)
+    samples = {"image": T("input.video", (2, 4, 3, 224, 224)), "instruction_input": instr, "answer": answers}
     with _cpu_backend.installed(), runtime.use_dtype("fp32"):
         loss, _, grads = training.loss_and_grads(model, samples)
-    assert abs(loss.item() - want_loss) <= 1e-4
-    assert set(grads) == set(want) == {n for n, _ in training.trainable_parameters(model)}
     assert any("BTAdapter" in n for n in grads)
-    for n, gr in grads.items():
-        assert (gr - want[n]).abs().max().item() <= 5e-4 * want[n].abs().max().item(), n
-    frozen_names = {n for n, _ in training.trainable_parameters(model, freeze_btadapter=True)}
-    assert frozen_names == {n for n in grads if "BTAdapter" not in n}
+    check_against_fixture(g, "btadapter", loss.item(), grads, 5e-4)
+    assert set(grads) == {n for n, _ in training.trainable_parameters(model)}
+    assert {n for n, _ in training.trainable_parameters(model, freeze_btadapter=True)} == {n for n in grads if "BTAdapter" not in n}
 
 
-@pytest.mark.parametrize("text", [False, True])
+@pytest.mark.parametrize("text", [True])       # the text-free variant runs inside the end-to-end BT-Adapter test
 def test_qformer_backward_to_image_tokens(text):
     """training_vision.qformer_backward: the dgrad-only sweep through the frozen Q-Former (2 layers: one with cross-attention, one
     without; with and without the text stream and its key mask) against autograd over the oracle's qformer_forward."""
@@ -198,34 +195,3 @@ def test_qformer_backward_to_image_tokens(text):
     assert (hq32.view(n, 32, 768) - out.detach()).abs().max() <= 2e-5 * out.abs().max()
     want = ev.grad.reshape(n * P, 1408)
     assert (d_enc - want).abs().max().item() <= 3e-4 * want.abs().max().item()
-
-
-def test_btadapter_branch_backward():
-    """training_vision.btadapter_backward: gradients of every BTAdapter* parameter (3 temporal + 3 spatial blocks, BTAdapter_cls,
-    BTAdapter_position) for a random output gradient, against autograd over the oracle's btadapter_forward (4-block ViT)."""
-    import _cpu_backend
-    from test_host_orchestration_cpu import CFGS, build
-    from stllm_amd import runtime, training_vision
-    cfg = CFGS["btadapter"]
-    model = build(cfg, vit_depth=4, qf_layers=2, llm_layers=1)
-    vit = model.model.stllm_model.visual_encoder
-    p = "model.stllm_model.visual_encoder."
-    sd = sd_from(shapes.stllm_model_shapes(4, 2, False, cfg["video_input"], False, vit_model=cfg["vit_model"], qf_vocab=32000))
-    x = T("input.video", (2, 3, 3, 224, 224))[:, :, :, :, :]            # B = 2 clips x T = 3 frames
-    x = torch.cat([x, x.flip(1)[:, :1]], dim=1)                         # T = 4 (not a [B,3,...] layout)
-    names = [n for n in sd if n.startswith(p) and "BTAdapter" in n]
-    for n in names:
-        sd[n].requires_grad_(True)
-    R = T("input.bt_dout", (2 * 4 * 257, 1408), 1.0)
-    with torch.enable_grad():
-        out = O.btadapter_forward(x, sd, p, 3).reshape(-1, 1408)
-        (out * R).sum().backward()
-    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
-        got_out, tape = training_vision.btadapter_forward_taped(vit, x)
-        grads = training_vision.btadapter_backward(vit, tape, R)
-    assert (got_out - out.detach()).abs().max() <= 3e-5 * out.abs().max()
-    assert set(grads) == set(names), set(grads) ^ set(names)
-    for n in names:
-        want = sd[n].grad
-        assert grads[n].shape == want.shape, n
-        assert (grads[n] - want).abs().max().item() <= 3e-4 * want.abs().max().item(), n
