@@ -262,7 +262,7 @@ def test_emulated_forward_attention_matches_contract(dtype, shape):
 
 
 # ---- skinny GEMM of the decode regime, incl. the staged M = 5..8 extension (beam search: 5 beams) -----------------------------
-@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 5), (torch.float16, 6), (torch.bfloat16, 8)])
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 5), (torch.float16, 8)])
 def test_gemv_rows_up_to_eight(dtype, M):
     from stllm_amd import pack
     N, K = 128, 520                                    # K % 512 != 0: one full 1024-byte step + a ragged one; K % 8 == 0

@@ -7,7 +7,8 @@ take the rest of the GPU suite down, and (b) the tests are xfail(strict=False): 
 for the next round.  Remove the marker once they have passed on an MI355X.
 
 1. every kernel case of test_kernels_emulated_cpu.py, through the real C ABI on cuda:0 (same tolerances);
-2. loss_and_grads on the device against the reference's gradient fixture (fp32 mode, 3e-4 of each tensor's abs-max), and
+2. loss_and_grads on the device against the reference's gradient fixture — MVM/mask, residual pooling + text, and the BT-Adapter
+   backbone with its adapter parameters — (fp32 mode, 5e-4 of each tensor's abs-max), and
    bf16 mode against the same fixture with the tolerance of bf16 GEMM operands (cosine similarity of every gradient tensor
    >= 0.995, loss within 2e-2)."""
 import os
@@ -44,11 +45,14 @@ import test_backward_cpu as TB
 from stllm_amd import runtime, training
 from test_model_gpu import build_stllm
 mode = sys.argv[1]
-for tag in ("mvm", "residual"):
+CASES = dict(TB.CASES, btadapter=(TB.BT_CASE, 4))
+DEPTHS = {"btadapter": (4, 2, 1)}
+for tag in ("mvm", "residual", "btadapter"):
     g = TB.golden("backward")
-    cfg, Tn = TB.CASES[tag]
+    cfg, Tn = CASES[tag]
     text = cfg["qformer_text_input"]
-    model = build_stllm(dict(cfg, image_size=224, num_query_token=32, max_txt_len=32, end_sym=" 2"), vit_depth=1, qf_layers=2, llm_layers=2)
+    vd, ql, ll = DEPTHS.get(tag, (1, 2, 2))
+    model = build_stllm(dict(cfg, image_size=224, num_query_token=32, max_txt_len=32, end_sym=" 2"), vit_depth=vd, qf_layers=ql, llm_layers=ll)
     instr, answers = TB.product_samples(g, tag, text)
     samples = {"image": TB.T("input.video", (2, Tn, 3, 224, 224)).cuda(), "instruction_input": instr, "answer": answers}
     if cfg.get("use_mask"):
@@ -58,7 +62,7 @@ for tag in ("mvm", "residual"):
     torch.cuda.synchronize()
     grads = {n: v.float().cpu() for n, v in grads.items()}
     if mode == "fp32":
-        TB.check_against_fixture(g, tag, loss.item(), grads, 3e-4)
+        TB.check_against_fixture(g, tag, loss.item(), grads, 5e-4)
     else:
         assert abs(loss.item() - g[f"{tag}.loss"][0]) < 2e-2 * abs(g[f"{tag}.loss"][0]), (loss.item(), g[f"{tag}.loss"][0])
         for n in (str(x) for x in g[f"{tag}.names"]):
@@ -78,4 +82,4 @@ for tag in ("mvm", "residual"):
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_training_step_on_device_matches_reference_gradients(mode):
     out = _child(["-c", _STEP, mode], timeout=900)
-    assert out.count("ok ") == 2, out[-2000:]
+    assert out.count("ok ") == 3, out[-2000:]
