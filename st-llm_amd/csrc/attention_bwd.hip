@@ -27,7 +27,6 @@
 
 namespace {
 
-constexpr int kD = 128;       // head dim of the MFMA path (Llama)
 constexpr int kT = 32;        // tile edge (queries / keys)
 
 template <typename T> __device__ __forceinline__ void ld8(const void* base, int64_t idx, float* f) {
@@ -271,34 +270,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(Ptr q, Ptr k, Ptr v, 
 // MFMA path (16-bit operands)
 // =========================================================================================================================
 constexpr int kNW = 4;                  // waves per workgroup: 128 queries (dQ) / 128 keys (dK/dV)
-constexpr int kKS = kD / 16;            // k-steps of a 128-deep contraction
-constexpr int kDB = kD / 32;            // 32-row blocks of a [128 x 32] transposed accumulator
-constexpr int kRowPitch = kD * 2 + 16;  // bytes per row-major tile row in LDS (conflict-free ds_read_b128)
+// head dim D <= DP, DP in {64, 96, 128} (88 is zero-padded to 96 in LDS / registers only, as in the forward kernel)
+template <int DP> struct MC {
+  static constexpr int KS = DP / 16;            // k-steps of a DP-deep contraction
+  static constexpr int DB = DP / 32;            // 32-row blocks of a [DP x 32] transposed accumulator
+  static constexpr int RowPitch = DP * 2 + 16;  // bytes per row-major tile row in LDS (conflict-free ds_read_b128)
+  static constexpr int NCH = 32 * (DP / 8);     // 16-byte chunks per tile
+  static constexpr int CPT = (NCH + 64 * kNW - 1) / (64 * kNW);   // ... per thread
+};
 constexpr int kTPitch = 32 * 2 + 8;     // bytes per row of a transposed tile [d][32 rows]
 constexpr float kNegBig = -1.0e30f;
 
 // Tiles are register-staged one tile AHEAD (as in the forward kernel): fetch_tile16 issues the global loads of the next tile before the
 // MFMA work of the current one, put_tile16 writes them to LDS at the top of the next iteration — HBM / L2 latency hides under compute.
-constexpr int kCPT = (32 * (kD / 8)) / (64 * kNW);      // 16-byte chunks per thread and tile
-template <typename T>
-__device__ __forceinline__ void fetch_tile16(i32x4* reg, const Ptr& t, int b, int h, int row0, int S, int tid) {
-  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)h * kD) * 2;
+template <typename T, int DP>
+__device__ __forceinline__ void fetch_tile16(i32x4* reg, const Ptr& t, int b, int h, int D, int row0, int S, int tid) {
+  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)h * D) * 2;
 #pragma unroll
-  for (int c = 0; c < kCPT; ++c) {
+  for (int c = 0; c < MC<DP>::CPT; ++c) {
     const int ch = tid + c * 64 * kNW;
     const int cc = ch >> 5, row = ch & 31;      // consecutive lanes = consecutive rows: conflict-free transposed writes
     const i32x4 z = {0, 0, 0, 0};
-    reg[c] = (row0 + row < S) ? *reinterpret_cast<const i32x4*>(base + ((int64_t)(row0 + row) * t.rs + cc * 8) * 2) : z;
+    reg[c] = (ch < MC<DP>::NCH && row0 + row < S && cc * 8 < D)
+                 ? *reinterpret_cast<const i32x4*>(base + ((int64_t)(row0 + row) * t.rs + cc * 8) * 2) : z;
   }
 }
 // row-major copy (rows_lds) and, if t_lds, the transposed copy [d][row]
+template <int DP>
 __device__ __forceinline__ void put_tile16(const i32x4* reg, char* rows_lds, char* t_lds, int tid) {
 #pragma unroll
-  for (int c = 0; c < kCPT; ++c) {
+  for (int c = 0; c < MC<DP>::CPT; ++c) {
     const int ch = tid + c * 64 * kNW;
+    if (ch >= MC<DP>::NCH) continue;
     const int cc = ch >> 5, row = ch & 31;
     const i32x4 x = reg[c];
-    *reinterpret_cast<i32x4*>(rows_lds + row * kRowPitch + cc * 16) = x;
+    *reinterpret_cast<i32x4*>(rows_lds + row * MC<DP>::RowPitch + cc * 16) = x;
     if (t_lds) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -310,13 +316,14 @@ __device__ __forceinline__ void put_tile16(const i32x4* reg, char* rows_lds, cha
   }
 }
 // this lane's B-operand fragments of row `row`: X[row][ks*16 + lh*8 .. +8], zero beyond S
-template <typename T>
-__device__ __forceinline__ void load_frags(i32x4* f, const Ptr& t, int b, int h, int row, int S, int lh) {
-  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)(row < S ? row : 0) * t.rs + (int64_t)h * kD) * 2;
+template <typename T, int DP>
+__device__ __forceinline__ void load_frags(i32x4* f, const Ptr& t, int b, int h, int D, int row, int S, int lh) {
+  const char* base = reinterpret_cast<const char*>(t.p) + ((int64_t)b * t.bs + (int64_t)(row < S ? row : 0) * t.rs + (int64_t)h * D) * 2;
 #pragma unroll
-  for (int ks = 0; ks < kKS; ++ks) {
+  for (int ks = 0; ks < MC<DP>::KS; ++ks) {
     const i32x4 z = {0, 0, 0, 0};
-    f[ks] = row < S ? *reinterpret_cast<const i32x4*>(base + (ks * 16 + lh * 8) * 2) : z;
+    const int d0 = ks * 16 + lh * 8;
+    f[ks] = (row < S && d0 < D) ? *reinterpret_cast<const i32x4*>(base + d0 * 2) : z;
   }
 }
 template <typename T> __device__ __forceinline__ float dot8(i32x4 a, i32x4 b) {
@@ -329,28 +336,28 @@ template <typename T> __device__ __forceinline__ float dot8(i32x4 a, i32x4 b) {
   }
   return s;
 }
-// X . Y^T for one 32x32 tile over the 128-deep contraction: A rows from a row-major LDS tile, B fragments in registers
-template <typename T> __device__ __forceinline__ f32x16 tile_nt(const char* rows_lds, const i32x4* bf, int li, int lh) {
+// X . Y^T for one 32x32 tile over the DP-deep contraction: A rows from a row-major LDS tile, B fragments in registers
+template <typename T, int DP> __device__ __forceinline__ f32x16 tile_nt(const char* rows_lds, const i32x4* bf, int li, int lh) {
   f32x16 s;
 #pragma unroll
   for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
-  for (int ks = 0; ks < kKS; ++ks) {
-    const i32x4 af = *reinterpret_cast<const i32x4*>(rows_lds + li * kRowPitch + (ks * 2 + lh) * 16);
+  for (int ks = 0; ks < MC<DP>::KS; ++ks) {
+    const i32x4 af = *reinterpret_cast<const i32x4*>(rows_lds + li * MC<DP>::RowPitch + (ks * 2 + lh) * 16);
     s = Elem<T>::mfma(af, bf[ks], s);
   }
   return s;
 }
 // acc^T[d][col] += X^T[d][row] . W[row][col]: A from the transposed LDS tile, B = the 32x32 accumulator `w` (rows x this lane's
 // column) packed to 16 bit; the accumulator register order IS the contraction order (see attention.hip)
-template <typename T> __device__ __forceinline__ void tile_tn(f32x16* acc, const char* t_lds, const f32x16& w, int li, int lh) {
+template <typename T, int DP> __device__ __forceinline__ void tile_tn(f32x16* acc, const char* t_lds, const f32x16& w, int li, int lh) {
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     i32x4 bf;
 #pragma unroll
     for (int e = 0; e < 4; ++e) bf[e] = (int)(Elem<T>::pack2(w[a * 8 + 2 * e], w[a * 8 + 2 * e + 1]));
 #pragma unroll
-    for (int i = 0; i < kDB; ++i) {
+    for (int i = 0; i < MC<DP>::DB; ++i) {
       const char* tp = t_lds + (i * 32 + li) * kTPitch + (16 * a + 4 * lh) * 2;
       const i32x2 lo = *reinterpret_cast<const i32x2*>(tp);
       const i32x2 hi = *reinterpret_cast<const i32x2*>(tp + 16);
@@ -360,12 +367,14 @@ template <typename T> __device__ __forceinline__ void tile_tn(f32x16* acc, const
   }
 }
 // lane holds acc^T[d = i*32 + 8g + 4lh + (0..3)][row]: 8-byte stores of 4 consecutive d
-template <typename T> __device__ __forceinline__ void store_acc_t(const f32x16* acc, const MPtr& t, int b, int h, int row, int lh, float mul) {
-  uint16_t* op = reinterpret_cast<uint16_t*>(t.p) + (int64_t)b * t.bs + (int64_t)row * t.rs + (int64_t)h * kD;
+template <typename T, int DP>
+__device__ __forceinline__ void store_acc_t(const f32x16* acc, const MPtr& t, int b, int h, int D, int row, int lh, float mul) {
+  uint16_t* op = reinterpret_cast<uint16_t*>(t.p) + (int64_t)b * t.bs + (int64_t)row * t.rs + (int64_t)h * D;
 #pragma unroll
-  for (int i = 0; i < kDB; ++i)
+  for (int i = 0; i < MC<DP>::DB; ++i)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (i * 32 + 8 * g + 4 * lh >= D) continue;      // D % 4 == 0
       uint2 pk;
       pk.x = Elem<T>::pack2(acc[i][4 * g + 0] * mul, acc[i][4 * g + 1] * mul);
       pk.y = Elem<T>::pack2(acc[i][4 * g + 2] * mul, acc[i][4 * g + 3] * mul);
@@ -373,12 +382,13 @@ template <typename T> __device__ __forceinline__ void store_acc_t(const f32x16* 
     }
 }
 
-template <typename T>
+template <typename T, int DP>
 __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, float* __restrict__ ws, int H,
-                                                                   int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
-  __shared__ __attribute__((aligned(16))) char k_lds[32 * kRowPitch];
-  __shared__ __attribute__((aligned(16))) char v_lds[32 * kRowPitch];
-  __shared__ __attribute__((aligned(16))) char kt_lds[kD * kTPitch];
+                                                                   int S, int D, float scale, int causal, const int32_t* __restrict__ kv_len) {
+  constexpr int kKS = MC<DP>::KS, kDB = MC<DP>::DB, kCPT = MC<DP>::CPT;
+  __shared__ __attribute__((aligned(16))) char k_lds[32 * MC<DP>::RowPitch];
+  __shared__ __attribute__((aligned(16))) char v_lds[32 * MC<DP>::RowPitch];
+  __shared__ __attribute__((aligned(16))) char kt_lds[DP * kTPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q_blk0 = blockIdx.x * (32 * kNW);
@@ -388,12 +398,12 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   const int kv_end = causal ? min(kvlen, q_blk0 + 32 * kNW) : kvlen;
   const float scale_log2 = scale * 1.4426950408889634f;
   i32x4 qf[kKS], dof[kKS];
-  load_frags<T>(qf, q, b, h, qrow, S, lh);
-  load_frags<T>(dof, dO, b, h, qrow, S, lh);
+  load_frags<T, DP>(qf, q, b, h, D, qrow, S, lh);
+  load_frags<T, DP>(dof, dO, b, h, D, qrow, S, lh);
   float delta = 0.0f;
   {
     i32x4 of[kKS];
-    load_frags<T>(of, o, b, h, qrow, S, lh);
+    load_frags<T, DP>(of, o, b, h, D, qrow, S, lh);
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) delta += dot8<T>(dof[ks], of[ks]);
     delta += __shfl_xor(delta, 32, 64);
@@ -401,14 +411,14 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   // ---- sweep 1: log-sum-exp of the scaled scores, log2 domain ------------------------------------------------------------
   float m_run = kNegBig, l_run = 0.0f;
   i32x4 kreg[kCPT], vreg[kCPT];
-  if (kv_end > 0) fetch_tile16<T>(kreg, k, b, h, 0, S, tid);
+  if (kv_end > 0) fetch_tile16<T, DP>(kreg, k, b, h, D, 0, S, tid);
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();                       // previous tile fully consumed
-    put_tile16(kreg, k_lds, nullptr, tid);
+    put_tile16<DP>(kreg, k_lds, nullptr, tid);
     __syncthreads();
-    if (kv0 + 32 < kv_end) fetch_tile16<T>(kreg, k, b, h, kv0 + 32, S, tid);
+    if (kv0 + 32 < kv_end) fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, S, tid);
     if (causal && kv0 > wave_q_last) continue;
-    f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
+    f32x16 s = tile_nt<T, DP>(k_lds, qf, li, lh);
     float mx = kNegBig;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -439,21 +449,21 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
   if (kv_end > 0) {
-    fetch_tile16<T>(kreg, k, b, h, 0, S, tid);
-    fetch_tile16<T>(vreg, v, b, h, 0, S, tid);
+    fetch_tile16<T, DP>(kreg, k, b, h, D, 0, S, tid);
+    fetch_tile16<T, DP>(vreg, v, b, h, D, 0, S, tid);
   }
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();
-    put_tile16(kreg, k_lds, kt_lds, tid);
-    put_tile16(vreg, v_lds, nullptr, tid);
+    put_tile16<DP>(kreg, k_lds, kt_lds, tid);
+    put_tile16<DP>(vreg, v_lds, nullptr, tid);
     __syncthreads();
     if (kv0 + 32 < kv_end) {
-      fetch_tile16<T>(kreg, k, b, h, kv0 + 32, S, tid);
-      fetch_tile16<T>(vreg, v, b, h, kv0 + 32, S, tid);
+      fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, S, tid);
+      fetch_tile16<T, DP>(vreg, v, b, h, D, kv0 + 32, S, tid);
     }
     if (causal && kv0 > wave_q_last) continue;
-    f32x16 s = tile_nt<T>(k_lds, qf, li, lh);
-    const f32x16 dp = tile_nt<T>(v_lds, dof, li, lh);
+    f32x16 s = tile_nt<T, DP>(k_lds, qf, li, lh);
+    const f32x16 dp = tile_nt<T, DP>(v_lds, dof, li, lh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -461,18 +471,20 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
       const float pr = dead ? 0.0f : __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2, -lse2));
       s[r] = pr * (dp[r] - delta);
     }
-    tile_tn<T>(acc, kt_lds, s, li, lh);
+    tile_tn<T, DP>(acc, kt_lds, s, li, lh);
   }
-  if (qrow < S) store_acc_t<T>(acc, dq, b, h, qrow, lh, scale);
+  if (qrow < S) store_acc_t<T, DP>(acc, dq, b, h, D, qrow, lh, scale);
 }
 
-template <typename T>
+template <typename T, int DP>
 __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws,
-                                                                    int H, int S, float scale, int causal, const int32_t* __restrict__ kv_len) {
-  __shared__ __attribute__((aligned(16))) char q_lds[32 * kRowPitch];
-  __shared__ __attribute__((aligned(16))) char do_lds[32 * kRowPitch];
-  __shared__ __attribute__((aligned(16))) char qt_lds[kD * kTPitch];
-  __shared__ __attribute__((aligned(16))) char dot_lds[kD * kTPitch];
+                                                                    int H, int S, int D, float scale, int causal,
+                                                                    const int32_t* __restrict__ kv_len) {
+  constexpr int kKS = MC<DP>::KS, kDB = MC<DP>::DB, kCPT = MC<DP>::CPT;
+  __shared__ __attribute__((aligned(16))) char q_lds[32 * MC<DP>::RowPitch];
+  __shared__ __attribute__((aligned(16))) char do_lds[32 * MC<DP>::RowPitch];
+  __shared__ __attribute__((aligned(16))) char qt_lds[DP * kTPitch];
+  __shared__ __attribute__((aligned(16))) char dot_lds[DP * kTPitch];
   __shared__ float st_lds[64];                               // (lse2, delta) of the 32 queries of the tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -482,8 +494,8 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
   const int kvlen = kv_len ? min(kv_len[b], S) : S;
   const float scale_log2 = scale * 1.4426950408889634f;
   i32x4 kf[kKS], vf[kKS];
-  load_frags<T>(kf, k, b, h, krow, S, lh);
-  load_frags<T>(vf, v, b, h, krow, S, lh);
+  load_frags<T, DP>(kf, k, b, h, D, krow, S, lh);
+  load_frags<T, DP>(vf, v, b, h, D, krow, S, lh);
   f32x16 accv[kDB], acck[kDB];
 #pragma unroll
   for (int i = 0; i < kDB; ++i)
@@ -494,21 +506,21 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
   i32x4 qreg[kCPT], oreg[kCPT];
   float streg = 0.0f;
   auto fetch = [&](int q0) {
-    fetch_tile16<T>(qreg, q, b, h, q0, S, tid);
-    fetch_tile16<T>(oreg, dO, b, h, q0, S, tid);
+    fetch_tile16<T, DP>(qreg, q, b, h, D, q0, S, tid);
+    fetch_tile16<T, DP>(oreg, dO, b, h, D, q0, S, tid);
     if (tid < 64) streg = (q0 + (tid >> 1) < S) ? wrow[2 * (q0 + (tid >> 1)) + (tid & 1)] : 0.0f;
   };
   if (q_first < S) fetch(q_first);
   for (int q0 = q_first; q0 < S; q0 += 32) {
     __syncthreads();
-    put_tile16(qreg, q_lds, qt_lds, tid);
-    put_tile16(oreg, do_lds, dot_lds, tid);
+    put_tile16<DP>(qreg, q_lds, qt_lds, tid);
+    put_tile16<DP>(oreg, do_lds, dot_lds, tid);
     if (tid < 64) st_lds[tid] = streg;
     __syncthreads();
     if (q0 + 32 < S) fetch(q0 + 32);
     if (causal && q0 + 31 < wave_k_first) continue;          // every query of the tile precedes every key of this wave
-    f32x16 s = tile_nt<T>(q_lds, kf, li, lh);                // s[r] = S[query (r&3)+8(r>>2)+4lh][key krow]
-    f32x16 ds = tile_nt<T>(do_lds, vf, li, lh);              // dP, same layout
+    f32x16 s = tile_nt<T, DP>(q_lds, kf, li, lh);                // s[r] = S[query (r&3)+8(r>>2)+4lh][key krow]
+    f32x16 ds = tile_nt<T, DP>(do_lds, vf, li, lh);              // dP, same layout
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ql = (r & 3) + 8 * (r >> 2) + 4 * lh, qq = q0 + ql;
@@ -517,22 +529,29 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
       ds[r] = pr * (ds[r] - st_lds[2 * ql + 1]);
       s[r] = pr;
     }
-    tile_tn<T>(accv, dot_lds, s, li, lh);                    // dV^T += dO^T P
-    tile_tn<T>(acck, qt_lds, ds, li, lh);                    // dK^T += Q^T dS
+    tile_tn<T, DP>(accv, dot_lds, s, li, lh);                    // dV^T += dO^T P
+    tile_tn<T, DP>(acck, qt_lds, ds, li, lh);                    // dK^T += Q^T dS
   }
   if (krow < S) {
-    store_acc_t<T>(accv, dv, b, h, krow, lh, 1.0f);
-    store_acc_t<T>(acck, dk, b, h, krow, lh, scale);
+    store_acc_t<T, DP>(accv, dv, b, h, D, krow, lh, 1.0f);
+    store_acc_t<T, DP>(acck, dk, b, h, D, krow, lh, scale);
   }
 }
 
-template <typename T>
-int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, float scale, int causal,
-                    const int32_t* kv_len, hipStream_t st) {
+template <typename T, int DP>
+int launch_bwd_mfma_dp(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int D, float scale,
+                       int causal, const int32_t* kv_len, hipStream_t st) {
   const dim3 grid((S + 32 * kNW - 1) / (32 * kNW), H, B), block(64 * kNW);
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<T>, grid, block, 0, st, q, k, v, o, dO, dq, ws, H, S, scale, causal, kv_len);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<T>, grid, block, 0, st, q, k, v, dO, dk, dv, ws, H, S, scale, causal, kv_len);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T, DP>), grid, block, 0, st, q, k, v, o, dO, dq, ws, H, S, D, scale, causal, kv_len);
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T, DP>), grid, block, 0, st, q, k, v, dO, dk, dv, ws, H, S, D, scale, causal, kv_len);
   return STLLM_OK;
+}
+template <typename T>
+int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int D, float scale, int causal,
+                    const int32_t* kv_len, hipStream_t st) {
+  if (D <= 64) return launch_bwd_mfma_dp<T, 64>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
+  if (D <= 96) return launch_bwd_mfma_dp<T, 96>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
+  return launch_bwd_mfma_dp<T, 128>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
 }
 
 template <typename T, int DP>
@@ -587,11 +606,11 @@ extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64
   const BwdDims dims{H, Sq, Skv, D, scale, causal, kv_len};
   int rc;
   const char* force = getenv("STLLM_ATTN_BWD_VALU");
-  const bool mfma = !(force && force[0] == '1') && D == kD && Sq == Skv;      // the Llama prefill shape
+  const bool mfma = !(force && force[0] == '1') && Sq == Skv;      // self-attention (Llama prefill, ViT / adapter blocks, Q-Former)
   switch (dtype) {
-    case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, scale, causal, kv_len, s)
+    case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, D, scale, causal, kv_len, s)
                                : launch_bwd_dp<bf16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
-    case STLLM_F16: rc = mfma ? launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, scale, causal, kv_len, s)
+    case STLLM_F16: rc = mfma ? launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, D, scale, causal, kv_len, s)
                               : launch_bwd_dp<f16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
     case STLLM_F32: rc = launch_bwd_dp<float>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
     default: stllm_set_error("stllm_attention_bwd: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;

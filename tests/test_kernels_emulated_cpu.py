@@ -343,11 +343,16 @@ def test_gelu_and_backward(dtype):
     close(C.gelu_bwd(x.float(), dy.float()), xv.grad, 1e-6, "contract vs autograd")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype,path", [(torch.float32, "default"), (torch.bfloat16, "default"), (torch.float16, "valu")])
 @pytest.mark.parametrize("shape", [dict(B=2, H=2, Sq=44, Skv=44, D=64, lens=[44, 37]),      # Q-Former self-attention [queries | text], key mask
-                                   dict(B=2, H=2, Sq=32, Skv=70, D=64, lens=None),          # Q-Former cross-attention, Sq != Skv
-                                   dict(B=1, H=2, Sq=70, Skv=70, D=88, lens=None)])         # EVA / BT-Adapter heads: 88 padded to 96 in LDS
-def test_attention_bwd_general_heads(dtype, shape):
+                                   dict(B=2, H=2, Sq=32, Skv=70, D=64, lens=None),          # Q-Former cross-attention, Sq != Skv (VALU kernels)
+                                   dict(B=1, H=2, Sq=150, Skv=150, D=88, lens=None)])       # EVA / BT-Adapter heads: 88 padded to 96; 2 workgroups
+def test_attention_bwd_general_heads(dtype, path, shape, monkeypatch):
+    # default path: MFMA kernels for 16-bit self-attention of any head dim, VALU kernels for fp32 and for Sq != Skv
+    if path == "valu":
+        monkeypatch.setenv("STLLM_ATTN_BWD_VALU", "1")
+    else:
+        monkeypatch.delenv("STLLM_ATTN_BWD_VALU", raising=False)
     B, H, Sq, Skv, D = shape["B"], shape["H"], shape["Sq"], shape["Skv"], shape["D"]
     HD = H * D
     q = rnd(B * Sq, HD, seed=72, dtype=dtype, scale=0.7)
