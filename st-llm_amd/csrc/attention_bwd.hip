@@ -29,22 +29,6 @@ namespace {
 
 constexpr int kT = 32;        // tile edge (queries / keys)
 
-template <typename T> __device__ __forceinline__ void ld8(const void* base, int64_t idx, float* f) {
-  if constexpr (Elem<T>::kIsF32) {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-    const float4 a = p[0], b = p[1];
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-  } else {
-    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      f[2 * e] = Elem<T>::unpack((uint16_t)(w[e] & 0xffffu));
-      f[2 * e + 1] = Elem<T>::unpack((uint16_t)(w[e] >> 16));
-    }
-  }
-}
-
 struct Ptr { const void* p; int64_t bs, rs; };
 struct MPtr { void* p; int64_t bs, rs; };
 
@@ -57,7 +41,7 @@ __device__ __forceinline__ void load_tile(float* lds, const Ptr& t, int b, int h
   for (int v = tid; v < kT * CPR; v += 256) {
     const int r = v / CPR, c = (v % CPR) * 8;
     float f[8];
-    if (row0 + r < rows && c < D) ld8<T>(t.p, off + (int64_t)(row0 + r) * t.rs + c, f);
+    if (row0 + r < rows && c < D) load8<T>(t.p, off + (int64_t)(row0 + r) * t.rs + c, f);
     else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = 0.0f;

@@ -9,45 +9,6 @@
 
 namespace {
 
-// ---- 8-element row vectors of the compute dtype <-> fp32 -------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void load8(const void* base, int64_t idx, float* f) {
-  if constexpr (Elem<T>::kIsF32) {
-    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-    const float4 a = p[0], b = p[1];
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
-  } else {
-    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + idx);
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      f[2 * e] = Elem<T>::unpack((uint16_t)(w[e] & 0xffffu));
-      f[2 * e + 1] = Elem<T>::unpack((uint16_t)(w[e] >> 16));
-    }
-  }
-}
-template <typename T> __device__ __forceinline__ void store8(void* base, int64_t idx, const float* f) {
-  if constexpr (Elem<T>::kIsF32) {
-    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + idx);
-    p[0] = make_float4(f[0], f[1], f[2], f[3]);
-    p[1] = make_float4(f[4], f[5], f[6], f[7]);
-  } else {
-    uint4 u;
-    u.x = Elem<T>::pack2(f[0], f[1]); u.y = Elem<T>::pack2(f[2], f[3]);
-    u.z = Elem<T>::pack2(f[4], f[5]); u.w = Elem<T>::pack2(f[6], f[7]);
-    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + idx) = u;
-  }
-}
-template <typename T> __device__ __forceinline__ void load4(const void* base, int64_t idx, float* f) {
-  if constexpr (Elem<T>::kIsF32) {
-    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-  } else {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
-    f[0] = Elem<T>::unpack((uint16_t)(u.x & 0xffffu)); f[1] = Elem<T>::unpack((uint16_t)(u.x >> 16));
-    f[2] = Elem<T>::unpack((uint16_t)(u.y & 0xffffu)); f[3] = Elem<T>::unpack((uint16_t)(u.y >> 16));
-  }
-}
-
 #define STLLM_DISPATCH_DTYPE(dtype, what, CALL)                                  \
   switch (dtype) {                                                               \
     case STLLM_BF16: { using T = bf16_t; CALL; } break;                          \

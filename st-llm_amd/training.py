@@ -380,25 +380,19 @@ class AdamW:
             dist.all_gather_into_tensor(self.flat, pshard.clone(), group=self.group)
         return norm
 
+    def state_dict(self):
+        """this rank's optimizer state (HF Trainer / DeepSpeed write one optimizer shard per rank too): step count, hyper-parameters,
+        the rank's slices of the moments; the masters live in the model's own state dict (trainable_state_dict)."""
+        return dict(step=self.step_no, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, world_size=self.world,
+                    rank=self.rank, n=self.n, m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone())
 
-def _adamw_state_dict(self):
-    """this rank's optimizer state (HF Trainer / DeepSpeed write one optimizer shard per rank too): step count, hyper-parameters,
-    the rank's slices of the moments; the masters live in the model's own state dict (trainable_state_dict)."""
-    return dict(step=self.step_no, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, world_size=self.world,
-                rank=self.rank, n=self.n, m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone())
-
-
-def _adamw_load_state_dict(self, sd):
-    if sd["world_size"] != self.world or sd["rank"] != self.rank or sd["n"] != self.n:
-        raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world_size']} ({sd['n']} parameters) does not fit rank "
-                         f"{self.rank}/{self.world} ({self.n})")
-    self.step_no = int(sd["step"])
-    self.m.copy_(sd["m"].to(self.m.device))
-    self.v.copy_(sd["v"].to(self.v.device))
-
-
-AdamW.state_dict = _adamw_state_dict
-AdamW.load_state_dict = _adamw_load_state_dict
+    def load_state_dict(self, sd):
+        if sd["world_size"] != self.world or sd["rank"] != self.rank or sd["n"] != self.n:
+            raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world_size']} ({sd['n']} parameters) does not fit rank "
+                             f"{self.rank}/{self.world} ({self.n})")
+        self.step_no = int(sd["step"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
 
 
 def cosine_lr(step, total_steps, base_lr, warmup_ratio=0.03):
