@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip"]
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip", "preprocess.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; }}\n"   # 160 KB of dynamic LDS
 
@@ -32,7 +32,7 @@ def build(force=False):
         with open(tu, "w") as fh:
             fh.write(head + text)
         tus.append(tu)
-    cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
+    cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
            "-I", HERE, "-I", CSRC] + tus + [os.path.join(HERE, "gemv_entry.cpp"), os.path.join(CSRC, "error.cpp"), "-o", lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -42,6 +42,12 @@ inline float __logf(float x) { return logf(x); }
 inline float __log2f(float x) { return log2f(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+// correctly rounded single operations (no contraction): plain IEEE ops on the host (-ffp-contract=off in the emulated build)
+inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)

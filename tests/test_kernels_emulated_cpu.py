@@ -370,3 +370,18 @@ def test_attention_bwd_general_heads(dtype, path, shape, monkeypatch):
     tol = 2e-5 if dtype == torch.float32 else 2 * TOL[dtype]
     close(gq, wq, tol, "dq")
     close(gkv, wkv, tol, "dk|dv")
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered bit for bit by tests/test_preprocess_gpu.py on the device")
+@pytest.mark.parametrize("H,W", [(40, 72), (75, 50)])
+def test_emulated_frame_preprocessing_is_bit_identical_to_the_oracle(H, W):
+    """preprocess.hip run emulated (coefficient tables in double with explicitly rounded ops, 22-bit fixed-point passes, crop,
+    normalise) == oracle/preprocess_oracle.py, which is pinned on the reference's own transform classes + Pillow."""
+    import numpy as np
+    import preprocess_oracle as P
+    g = torch.Generator().manual_seed(80)
+    frames = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8)
+    want = torch.from_numpy(P.video_transform(frames.numpy())).view(-1, 3, 224, 224)
+    with _hipemu.emulated() as hip:
+        got = hip.preprocess_frames(frames)
+    assert np.array_equal(got.numpy(), want.numpy())
