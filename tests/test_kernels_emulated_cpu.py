@@ -265,7 +265,7 @@ def test_emulated_forward_attention_matches_contract(dtype, shape):
 @pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 5), (torch.float16, 8)])
 def test_gemv_rows_up_to_eight(dtype, M):
     from stllm_amd import pack
-    N, K = 128, 520                                    # K % 512 != 0: one full 1024-byte step + a ragged one; K % 8 == 0
+    N, K = 128, 576                                    # K % 512 != 0: one full 1024-byte step + a ragged one; K % 64 == 0 (stllm_gemm)
     a = rnd(M, K, seed=50, dtype=dtype, scale=0.5)
     w = rnd(N, K, seed=51, dtype=dtype, scale=0.05)
     bias = rnd(N, seed=52)
