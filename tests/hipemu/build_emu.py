@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip", "preprocess.hip"]
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip", "preprocess.hip", "gemm.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; }}\n"   # 160 KB of dynamic LDS
 
@@ -16,10 +16,15 @@ DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libstllm_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "gemv_entry.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "p8_stubs.cpp")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
     tus = []
+    # headers with inline ISA get the same treatment, as a patched copy that shadows the original for the emulated TUs only
+    hdr = open(os.path.join(CSRC, "gemm_common.h")).read()
+    hdr = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "", hdr)
+    with open(os.path.join(OUT, "gemm_common.h"), "w") as fh:
+        fh.write(hdr)
     for f in KERNEL_SOURCES:
         text = open(os.path.join(CSRC, f)).read()
         m = re.search(r"extern\s+__shared__[^;]*?(\w+)\s+smem\[\]", text)
@@ -28,12 +33,15 @@ def build(force=False):
             ty = m.group(1)
             head = DYN.format(type=ty, n=163840 // (4 if ty == "float" else 1))
         text = re.sub(r"extern\s+__shared__", "EMU_DYN_SHARED", text)
+        # inline ISA: a barrier that does not drain the LDS-DMA queue is a plain barrier here; bare waits vanish (copies are synchronous)
+        text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\)', "__syncthreads()", text)
+        text = re.sub(r'asm volatile\("s_waitcnt [a-z]+cnt\(\d+\)" ::: "memory"\)', "((void)0)", text)
         tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
         with open(tu, "w") as fh:
             fh.write(head + text)
         tus.append(tu)
     cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
-           "-I", HERE, "-I", CSRC] + tus + [os.path.join(HERE, "gemv_entry.cpp"), os.path.join(CSRC, "error.cpp"), "-o", lib]
+           "-I", HERE, "-I", OUT, "-I", CSRC] + tus + [os.path.join(HERE, "p8_stubs.cpp"), os.path.join(CSRC, "error.cpp"), "-o", lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulation build failed:\n" + r.stderr[-4000:])

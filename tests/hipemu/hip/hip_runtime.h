@@ -53,7 +53,17 @@ inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32_f32(a, b, c)
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_med3(a, b, c)
-#define __builtin_amdgcn_global_load_lds(g, l, n, o, a) ((void)0)
+#define __builtin_amdgcn_global_load_lds(g, l, n, o, a) emu_global_load_lds(g, l, n, o)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_fetch_or(p, v, order, scope) (*(p) |= (v))
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()   /* lanes are independent threads here: make it a real barrier */
 
@@ -78,6 +88,10 @@ inline float __shfl_xor(float v, int mask, int width = 64) {
   const float r = emu_cur->xch[t ^ mask];
   bar.arrive_and_wait();
   return r;
+}
+// LDS-DMA (global_load_lds): every lane copies `n` bytes from its own global address to the wave-uniform LDS base + lane * n
+template <class G, class L> inline void emu_global_load_lds(G g, L l, int n, int off) {
+  std::memcpy((char*)(l) + off + (threadIdx.x & 63) * n, (const char*)(g), n);
 }
 inline int __any(int pred) {                                  // wave vote
   const int t = threadIdx.x, w0 = t & ~63;
@@ -141,6 +155,12 @@ enum hipMemcpyKind { hipMemcpyDeviceToHost = 2 };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount = 6; };          // a small persistent grid keeps the emulation cheap
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 template <typename K, typename... A>
 void emu_launch(K kern, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t /*stream*/, A... args) {

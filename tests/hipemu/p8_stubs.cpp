@@ -1,0 +1,8 @@
+// TEST-ONLY: the phased GEMM (gemm_p8.inc: LDS-DMA rings, hardware registers, cross-workgroup flags) cannot run in the emulator;
+// the emulated library reports it as unsupported so that stllm_gemm falls back to the 128x128 kernels of gemm.hip, which can.
+#include "gemm_common.h"
+
+int stllm_gemm_p8_launch_bf16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
+int stllm_gemm_p8_launch_f16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
+float stllm_gemm_p8_estimate_us(int, int, int, int, int* miw) { if (miw) *miw = 4; return 1.0e30f; }
+extern "C" int stllm_gemm_plan(int, int, int, int, int, int*) { return STLLM_ERR_UNSUPPORTED; }

@@ -32,7 +32,7 @@ def _child(args, timeout, env_extra=None):
 @pytest.mark.gpu
 @FIRST_RUN
 def test_training_kernels_on_device():
-    out = _child(["-m", "pytest", "tests/test_kernels_emulated_cpu.py", "-q", "-x", "-k", "not emulated_kernels", "-p", "no:cacheprovider"],
+    out = _child(["-m", "pytest", "tests/test_kernels_emulated_cpu.py", "-q", "-x", "-k", "not entirely_on_emulated_kernels", "-p", "no:cacheprovider"],
                  timeout=900, env_extra={"STLLM_TRAIN_KERNELS_ON_DEVICE": "1"})
     assert " passed" in out and "failed" not in out, out[-2000:]
 
