@@ -275,8 +275,7 @@ def test_gemv_rows_up_to_eight(dtype, M):
     resid = rnd(M, N, seed=53)
     cos, sin = pack.rope_tables(4, 128)
     with _hipemu.emulated() as hip:
-        if _hipemu.ON_DEVICE:
-            hip.set_option("gemm_gemv", 2)
+        hip.set_option("gemm_gemv", 2)                  # the real dispatch of stllm_gemm: GEMV kernel up to M = 8
         try:
             cases = {
                 "store": hip.gemm(a, w, dtype=dtype, bias=bias),
@@ -284,9 +283,9 @@ def test_gemv_rows_up_to_eight(dtype, M):
                 "swiglu": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_SWIGLU),
                 "rope": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_ROPE, rope=(cos[1:2], sin[1:2]), rope_seq=1, rope_cols=128),
             }
+            assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel"), hip.lib().stllm_last_kernel()
         finally:
-            if _hipemu.ON_DEVICE:
-                hip.set_option("gemm_gemv", -1)
+            hip.set_option("gemm_gemv", -1)
     want = {
         "store": C.gemm(a, w, dtype=dtype, bias=bias),
         "resid": C.gemm(a, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone()),
