@@ -403,8 +403,9 @@ def fx_backward():
                           video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
                           qformer_text_input=True, max_txt_len=32, end_sym=" 2", vit_precision="fp32"), 8),
         # the backbone of 4 of the 5 shipped training configs: visual_encoder.BTAdapter* stay trainable (st_llm.py:257-261)
+        # and with the model block of config/instructblipbase_stllm_qa.yaml: video_input all, use_mask, mvm_decode, qformer_text_input
         "btadapter": (dict(vit_model="eva_btadapter_g", image_size=224, num_query_token=32, llama_model="", video_input="all",
-                           use_mask=False, mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2",
+                           use_mask=True, mvm_decode=True, qformer_text_input=True, max_txt_len=32, end_sym=" 2",
                            vit_precision="fp32"), 4),
     }
     depths = {"btadapter": (4, 2, 1)}                      # (ViT blocks, Q-Former layers, Llama layers); default (1, 2, 2)

@@ -18,7 +18,7 @@ CASES = {
     "residual": (dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=False, mvm_decode=False,
                       qformer_text_input=True), 8),
 }
-BT_CASE = dict(vit_model="eva_btadapter_g", video_input="all", use_mask=False, mvm_decode=False, qformer_text_input=False)
+BT_CASE = dict(vit_model="eva_btadapter_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=True)   # = instructblipbase_stllm_qa.yaml
 FROZEN = ("model.stllm_model.visual_encoder", "model.stllm_model.ln_vision", "model.stllm_model.Qformer",
           "model.stllm_model.query_tokens")
 
@@ -146,7 +146,8 @@ def test_mean_pooling_backward_and_one_optimizer_step():
 
 
 def test_btadapter_backbone_end_to_end_matches_reference():
-    """eva_btadapter_g backbone (4 of the 5 shipped training configs): loss_and_grads carries the gradient through llama_proj, the
+    """The reference's main training config (config/instructblipbase_stllm_qa.yaml: eva_btadapter_g backbone, Q-Former text input,
+    video_input all, dynamic masking + MVM loss): loss_and_grads carries the gradient through llama_proj, the
     frozen Q-Former and ln_vision into the adapter branch; every trainable tensor (LLM, projector, all BTAdapter*) matches the
     REFERENCE's own loss.backward() (tests/golden/backward.npz, case "btadapter": 4 ViT blocks, 3 adapter layers, 1 Llama layer).
     freeze_btadapter=True names exactly the non-adapter entries."""
@@ -155,8 +156,9 @@ def test_btadapter_backbone_end_to_end_matches_reference():
     from stllm_amd import runtime, training
     g = golden("backward")
     model = build(dict(BT_CASE, image_size=224, num_query_token=32, max_txt_len=32, end_sym=" 2"), vit_depth=4, qf_layers=2, llm_layers=1)
-    instr, answers = product_samples(g, "btadapter", False)
-    samples = {"image": T("input.video", (2, 4, 3, 224, 224)), "instruction_input": instr, "answer": answers}
+    instr, answers = product_samples(g, "btadapter", True)
+    samples = {"image": T("input.video", (2, 4, 3, 224, 224)), "instruction_input": instr, "answer": answers,
+               "mask": torch.from_numpy(g["btadapter.mask"])}
     with _cpu_backend.installed(), runtime.use_dtype("fp32"):
         loss, _, grads = training.loss_and_grads(model, samples)
     assert any("BTAdapter" in n for n in grads)

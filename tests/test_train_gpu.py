@@ -56,7 +56,7 @@ for tag in sys.argv[2].split(","):
     instr, answers = TB.product_samples(g, tag, text)
     samples = {"image": TB.T("input.video", (2, Tn, 3, 224, 224)).cuda(), "instruction_input": instr, "answer": answers}
     if cfg.get("use_mask"):
-        samples["mask"] = torch.from_numpy(g[f"{tag}.mask"])
+        samples["mask"] = torch.from_numpy(g[f"{tag}.mask"])     # (the BT-Adapter case is the masked / MVM / text config too)
     with runtime.use_dtype(mode):
         loss, loss_mvm, grads = training.loss_and_grads(model, samples)
     torch.cuda.synchronize()
