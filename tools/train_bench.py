@@ -22,19 +22,22 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--backbone", default="eva_clip_g", choices=["eva_clip_g", "eva_btadapter_g"],
+                    help="eva_btadapter_g = the reference's main training config: the BTAdapter* parameters train too")
+    ap.add_argument("--text", action="store_true", help="Q-Former text input (instructblip_* model types)")
     a = ap.parse_args()
     from stllm_amd import runtime, synth, training
     from stllm_amd.models import st_llm
     from stllm_amd.models.blip2 import Blip2Base
     Blip2Base.vit_depth = a.vit_depth
-    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=True, mvm_decode=True,
-               qformer_text_input=False, max_txt_len=64, end_sym=" 2", llama_model=dict(num_hidden_layers=a.layers))
+    cfg = dict(vit_model=a.backbone, image_size=224, num_query_token=32, video_input="all", use_mask=True, mvm_decode=True,
+               qformer_text_input=a.text, max_txt_len=64, end_sym=" 2", llama_model=dict(num_hidden_layers=a.layers))
     model = st_llm.STLLMForCausalLM.from_config(cfg, device="cuda")
     synth.fill_module_(model, 0, "")
     g = torch.Generator().manual_seed(0)
     ids = lambda n: " ".join(str(int(x)) for x in torch.randint(3, 32000, (n,), generator=g))
     samples = {"image": torch.randn(a.batch, a.frames, 3, 224, 224, device="cuda"),
-               "instruction_input": [f"{ids(7)}<ImageHere>{ids(24)}" for _ in range(a.batch)], "answer": [ids(31) for _ in range(a.batch)]}
+               "instruction_input": [f"{ids(7)}<ImageHere>{ids(24)}" + (f" Human: {ids(12)} ###" if a.text else "") for _ in range(a.batch)], "answer": [ids(31) for _ in range(a.batch)]}
     opt = training.AdamW(list(training.trainable_parameters(model)), lr=2e-5)
     with runtime.use_dtype(a.dtype):
         for step in range(a.steps + 1):
