@@ -69,8 +69,11 @@ for tag in sys.argv[2].split(","):
             gr = grads[n]
             got = TB.sub(gr, 97, 101) if gr.dim() == 2 else TB.sub(gr, 29)
             want = g[f"{tag}.slice.{n}"]
-            cs = float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
-            assert cs >= 0.995, (n, cs)
+            if np.linalg.norm(want) < 1e-12:            # e.g. embed_tokens: the sampled rows may hold no token of the batch
+                assert np.linalg.norm(got) < 1e-6, n
+            else:
+                cs = float((got * want).sum() / (np.linalg.norm(got) * np.linalg.norm(want) + 1e-30))
+                assert cs >= 0.995, (n, cs)
             st = g[f"{tag}.stats.{n}"]
             assert abs(TB.stats(gr)[0] - st[0]) <= 5e-2 * st[0], (n, TB.stats(gr)[0], st[0])
     print("ok", tag, mode, loss.item())
