@@ -26,8 +26,10 @@ class _DeviceProxy:
     """stllm_amd.hip on the real GPU for tests written against CPU tensors: tensor arguments are copied to the device, the real
     entry point runs, every tensor argument is copied back (in-place results) and tensor results are returned on the CPU."""
 
-    def __init__(self, hip):
+    def __init__(self, hip, to_device=None, sync=None):
         self._hip = hip
+        self._to_device = to_device or (lambda x: x.cuda())
+        self._sync = sync
 
     def __getattr__(self, name):
         import torch
@@ -38,7 +40,7 @@ class _DeviceProxy:
 
             def mv(x):
                 if isinstance(x, torch.Tensor):
-                    y = x.cuda()
+                    y = self._to_device(x)
                     moved.append((x, y))
                     return y
                 if isinstance(x, (tuple, list)):
@@ -52,7 +54,7 @@ class _DeviceProxy:
                     return type(r)(back(x) for x in r)
                 return r
             r = f(*[mv(x) for x in a], **{kk: mv(v) for kk, v in k.items()})
-            torch.cuda.synchronize()
+            (self._sync or torch.cuda.synchronize)()
             for x, y in moved:
                 x.copy_(y.cpu())
             return back(r)

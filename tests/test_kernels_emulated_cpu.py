@@ -436,3 +436,25 @@ def test_emulated_patch_embed_gemm():
         hip.gemm(None, w, dtype=torch.bfloat16, epilogue=C.EPI_PATCH, bias=bias, out=got, frames=frames, pos_embed=pos, n_frames=1)
     close(got[1:], want[1:], TOL[torch.bfloat16], "patch embed")
     assert not got[0].abs().max()                       # the CLS row is written by stllm_vit_cls_rows, not by the GEMM
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="dry run of the device-mode plumbing")
+def test_device_proxy_plumbing_dry_run():
+    """tests/test_train_gpu.py runs this file on the GPU through _hipemu._DeviceProxy (copy in, call, copy every tensor back).  Here
+    the same proxy wraps the emulated library with 'device' = a detached clone: in-place outputs written into views, tuple kwargs and
+    tensor results must come back exactly as from a direct call."""
+    x, gamma, dy = rnd(5, 136, seed=100), rnd(136, seed=101) + 1.0, rnd(5, 136, seed=102)
+    dx_direct, dx_proxy = rnd(5, 136, seed=103), rnd(5, 136, seed=103)
+    B, H, S, D = 1, 1, 33, 64
+    qkv, do = rnd(S, 3 * D, seed=104, scale=0.7), rnd(S, D, seed=105)
+    o = C.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5)
+    d_direct, d_proxy = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    kw = dict(B=B, H=H, S=S, D=D, scale=D ** -0.5, causal=False)
+    with _hipemu.emulated() as hip:
+        proxy = _hipemu._DeviceProxy(hip, to_device=lambda t: t.detach().clone(), sync=lambda: None)
+        g1 = hip.rmsnorm_bwd(x, gamma, 1e-6, dy, dx_direct, accumulate=True)                 # in-place output + tensor result
+        g2 = proxy.rmsnorm_bwd(x, gamma, 1e-6, dy, dx_proxy, accumulate=True)
+        for api, d in ((hip, d_direct), (proxy, d_proxy)):                                    # outputs written into column-slice views
+            api.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, d[:, :D], d[:, D:2 * D], d[:, 2 * D:], **kw)
+    assert torch.equal(g1, g2) and torch.equal(dx_direct, dx_proxy)
+    assert d_direct.abs().max() > 0 and torch.equal(d_direct, d_proxy)
