@@ -296,6 +296,12 @@ int stllm_gelu(int dtype, const void* x, int64_t ldx, void* out, int64_t ldo, in
 int stllm_gelu_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, int rows, int cols,
                    void* stream);
 
+/* x[r, :] *= scale[idx ? idx[r] : r / rows_per_group], in place (T [rows, cols], cols % 8 == 0): timm's drop_path as called by the
+ * BT-Adapter blocks in train mode (eva_vit.py:30-38, eva_btadapter.py:274-280, 303) — per-sample keep mask / keep_prob — and, being
+ * linear and diagonal, its own backward. */
+int stllm_scale_rows(int dtype, void* x, int64_t ldx, const float* scale, const int32_t* idx, int rows_per_group, int rows, int cols,
+                     void* stream);
+
 /* Transpose of stllm_mean_t up to the 1/T factor: dst[b, t, j] += scale * src[b, j]  (f32, J % 4 == 0). */
 int stllm_bcast_add_t(float* dst, const float* src, int B, int T, int64_t J, float scale, void* stream);
 

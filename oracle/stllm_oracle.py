@@ -125,20 +125,26 @@ def ln_vision(x: Tensor, sd: SD, p: str = "ln_vision") -> Tensor:
 # =====================================================================================
 # BT-Adapter visual backbone  (stllm/models/eva_btadapter.py)
 # =====================================================================================
-def _bt_temp(x: Tensor, T: int, sd: SD, p: str) -> Tensor:
-    """BTAdapter_Temp.forward eva_btadapter.py:295-310 (norm eps 1e-6, :284)."""
+def _drop(x: Tensor, m: Optional[Tensor]) -> Tensor:
+    """DropPath (eva_vit.py:30-38 -> timm.layers.drop_path, not in the reference tree; timm's published algorithm): per-sample
+    x * bernoulli(keep) / keep.  Here the per-sample factor m (0 or 1 / keep_prob) is INJECTED, like the dynamic mask; None = eval."""
+    return x if m is None else x * m.view((-1,) + (1,) * (x.ndim - 1))
+
+
+def _bt_temp(x: Tensor, T: int, sd: SD, p: str, drop: Optional[Tensor] = None) -> Tensor:
+    """BTAdapter_Temp.forward eva_btadapter.py:295-310 (norm eps 1e-6, :284).  drop: [b * patches] factors (:303)."""
     residual = x[:, 1:, :]
     cls = x[:, :1, :]
     b, pt, m = residual.shape
     pch = pt // T
     h = residual.reshape(b * pch, T, m)
-    h = vit_attention(layer_norm(h, sd, p + "norm1", 1e-6), sd, p + "attn.")
+    h = _drop(vit_attention(layer_norm(h, sd, p + "norm1", 1e-6), sd, p + "attn."), drop)
     h = _lin(h, sd, p + "temporal_fc")
     h = h.reshape(b, pch * T, m) + residual
     return torch.cat((cls, h), 1)
 
 
-def _bt_spatial(x: Tensor, T: int, sd: SD, p: str) -> Tensor:
+def _bt_spatial(x: Tensor, T: int, sd: SD, p: str, drop_s: Optional[Tensor] = None, drop_o: Optional[Tensor] = None) -> Tensor:
     """BTAdapter_Spatial.forward eva_btadapter.py:261-281.  NOTE: built through Block's default
     norm_layer=nn.LayerNorm (eva_btadapter.py:259, eva_vit.py:154) => eps **1e-5**, unlike the
     ViT blocks (1e-6) whose weights it clones (:89-99)."""
@@ -150,18 +156,19 @@ def _bt_spatial(x: Tensor, T: int, sd: SD, p: str) -> Tensor:
     cls = cls0.unsqueeze(1).repeat(1, T, 1, 1).reshape(b * T, 1, m)
     q = q.reshape(b, pch, T, m).permute(0, 2, 1, 3).reshape(b * T, pch, m)  # 'b (p t) m -> (b t) p m'
     h = torch.cat((cls, q), 1)
-    h = vit_attention(layer_norm(h, sd, p + "norm1", 1e-5), sd, p + "attn.")
+    h = _drop(vit_attention(layer_norm(h, sd, p + "norm1", 1e-5), sd, p + "attn."), drop_s)       # :274, per (b t) sample
     cls = h[:, :1, :].reshape(b, T, 1, m).mean(1)
     rs = h[:, 1:, :].reshape(b, T, pch, m).permute(0, 2, 1, 3).reshape(b, pch * T, m)  # '(b t) p m -> b (p t) m'
     x = residual + torch.cat((cls, rs), 1)
     x = x + vit_mlp(layer_norm(x, sd, p + "norm2", 1e-5), sd, p + "mlp.")
-    return x
+    return _drop(x, drop_o)                                                                           # :280, the whole block output per b
 
 
 def btadapter_forward(x: Tensor, sd: SD, p: str = "", adapter_depth: int = 3,
-                      return_branches: bool = False):
+                      return_branches: bool = False, drop=None):
     """EVAVisionTransformer_BTAdapter.forward/forward_features/forward_branch/init_input
-    eva_btadapter.py:147-255.  x: [B,T,3,224,224] or 4-D [T,3,224,224] (B=1)."""
+    eva_btadapter.py:147-255.  x: [B,T,3,224,224] or 4-D [T,3,224,224] (B=1).
+    drop: train-mode stochastic depth, one dict per adapter layer {"t": [B*256], "s": [B*T], "o": [B]} of injected factors."""
     if x.ndim == 5:
         if x.shape[1] == 3:  # reference quirk (:235-237): dim-1 == 3 is read as B,C,T,H,W
             x = x.permute(0, 2, 1, 3, 4)
@@ -194,8 +201,9 @@ def btadapter_forward(x: Tensor, sd: SD, p: str = "", adapter_depth: int = 3,
                 xp = xp + sd[p + "BTAdapter_position.weight"][:t]
                 xp = xp.reshape(b, l * t, d)  # '(b l) t d -> b (l t) d'
                 xb = torch.cat(((cls_x + cls_br) / 2, xp), dim=1)
-            xb = _bt_temp(xb, T, sd, f"{p}BTAdapter_T.{j}.")
-            xb = _bt_spatial(xb, T, sd, f"{p}BTAdapter_S.{j}.")
+            dj = drop[j] if drop is not None else {}
+            xb = _bt_temp(xb, T, sd, f"{p}BTAdapter_T.{j}.", dj.get("t"))
+            xb = _bt_spatial(xb, T, sd, f"{p}BTAdapter_S.{j}.", dj.get("s"), dj.get("o"))
             branch = xb
             branches.append(xb)
     pch = h.shape[1] - 1

@@ -285,6 +285,22 @@ __global__ __launch_bounds__(256) void gelu_kernel(const void* __restrict__ x, i
   store8<T>(out, (int64_t)row * ldo + j, a);
 }
 
+// ---- per-row scaling by a per-group factor (stochastic depth: x * keep_mask / keep_prob per sample; its own transpose) ----------
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_kernel(void* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                                         const int32_t* __restrict__ idx, int rows_per_group, int M, int N) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = N >> 3;
+  if (t >= (int64_t)M * per_row) return;
+  const int row = (int)(t / per_row), j = (int)(t % per_row) * 8;
+  const float s = scale[idx ? idx[row] : row / rows_per_group];
+  float a[8];
+  load8<T>(x, (int64_t)row * ldx + j, a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] *= s;
+  store8<T>(x, (int64_t)row * ldx + j, a);
+}
+
 // ---- small elementwise pieces -------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const void* __restrict__ dy, int64_t lddy, const void* __restrict__ y, int64_t ldy,
@@ -520,6 +536,18 @@ extern "C" int stllm_gelu_bwd(int dtype, const void* x, int64_t ldx, const void*
                        hipLaunchKernelGGL((gelu_kernel<T, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, ldx, dy, lddy, dx, lddx,
                                           rows, cols));
   STLLM_CHECK_LAUNCH("stllm_gelu_bwd");
+  return STLLM_OK;
+}
+
+extern "C" int stllm_scale_rows(int dtype, void* x, int64_t ldx, const float* scale, const int32_t* idx, int rows_per_group, int rows, int cols,
+                                void* stream) {
+  STLLM_CHECK_ARG(x && scale && rows > 0 && cols > 0 && cols % 8 == 0 && (idx || rows_per_group > 0), "stllm_scale_rows: bad args");
+  STLLM_CHECK_ARG(vec_ok(x, ldx, dtype), "stllm_scale_rows: rows must be 16-byte aligned");
+  const int64_t n = (int64_t)rows * (cols / 8);
+  STLLM_DISPATCH_DTYPE(dtype, "stllm_scale_rows",
+                       hipLaunchKernelGGL(scale_rows_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), x, ldx, scale, idx,
+                                          rows_per_group, rows, cols));
+  STLLM_CHECK_LAUNCH("stllm_scale_rows");
   return STLLM_OK;
 }
 

@@ -388,7 +388,7 @@ def set_option(key, value):
 # current stream, no fallback.
 TRAIN_EXPORTS = ["stllm_transpose", "stllm_norm_bwd_workspace_bytes", "stllm_rmsnorm_bwd", "stllm_layernorm_bwd", "stllm_swiglu",
                  "stllm_swiglu_bwd", "stllm_rope_bwd", "stllm_attention_bwd_workspace_bytes", "stllm_attention_bwd", "stllm_cross_entropy_bwd", "stllm_scatter_add_rows",
-                 "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_gelu", "stllm_gelu_bwd", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
+                 "stllm_cosine_rows_bwd", "stllm_colsum", "stllm_relu_bwd", "stllm_gelu", "stllm_gelu_bwd", "stllm_scale_rows", "stllm_bcast_add_t", "stllm_adamw", "stllm_sumsq"]
 EXPORTS += TRAIN_EXPORTS
 _train_bound = False
 
@@ -415,6 +415,7 @@ def _tlib():
         L.stllm_colsum.argtypes = [i, p, i64, p, i, i, p, i64, p]
         L.stllm_relu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
         L.stllm_gelu.argtypes = [i, p, i64, p, i64, i, i, p]
+        L.stllm_scale_rows.argtypes = [i, p, i64, p, p, i, i, i, p]
         L.stllm_gelu_bwd.argtypes = [i, p, i64, p, i64, p, i64, i, i, p]
         L.stllm_bcast_add_t.argtypes = [p, p, i, i, i64, f, p]
         L.stllm_adamw.argtypes = [p, p, p, p, p, i, i64, f, f, f, f, f, i, f, p]
@@ -593,6 +594,17 @@ def gelu_bwd(x, dy):
     _check(_tlib().stllm_gelu_bwd(dtype_code(x.dtype), _p(x), x.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), M, N, _stream()),
            "stllm_gelu_bwd")
     return out
+
+
+def scale_rows(x, scale, *, rows_per_group=0, idx=None):
+    """x[r] *= scale[idx[r]] (or scale[r // rows_per_group]) in place; x [M,N] any dtype, scale f32 — stochastic depth and its backward"""
+    _req(x, None, "x"); _req(scale, torch.float32, "scale")
+    if idx is not None:
+        _req(idx, torch.int32, "idx")
+    M, N = x.shape
+    _check(_tlib().stllm_scale_rows(dtype_code(x.dtype), _p(x), x.stride(0), _p(scale), _p(idx), rows_per_group, M, N, _stream()),
+           "stllm_scale_rows")
+    return x
 
 
 def bcast_add_t(dst, src, scale):

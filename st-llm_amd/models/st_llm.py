@@ -144,7 +144,7 @@ class STLLMModel(Blip2Base):
         else:
             if taped_vision:   # training of the BTAdapter* parameters: keep the branch's activations (training_vision.py)
                 from .. import training_vision
-                feats, self._tape["bt_tape"] = training_vision.btadapter_forward_taped(self.visual_encoder, image)
+                feats, self._tape["bt_tape"] = training_vision.btadapter_forward_taped(self.visual_encoder, image, self._tape.get("drop_path"))
             else:
                 feats = self.visual_encoder.forward_flat(image)
             n = feats.shape[0] // 257

@@ -20,8 +20,8 @@ MI355X-first choices:
   * q/k gradients are rotated back by `stllm_rope_bwd` in the packed head layout, weight gradients are produced in the packed
     layouts of pack.py and un-permuted once per step into the reference's parameter layout (index permutations only).
 BT-Adapter parameters (model_type *_btadapter — 4 of the 5 shipped training configs): their gradient goes back through llama_proj,
-the frozen Q-Former and ln_vision into the adapter branch (training_vision.py).  The reference's stochastic depth in the adapter
-blocks (drop_path 0.1 in train mode, eva_btadapter.py:260) is not applied: the step is the deterministic (eval-mode) one.
+the frozen Q-Former and ln_vision into the adapter branch (training_vision.py).  The adapter blocks' train-mode stochastic depth
+(DropPath 0.1, eva_btadapter.py:259) is applied when per-sample factors are passed (`drop_path=`); default: the deterministic step.
 
 Layout of the result: {reference parameter name: fp32 gradient in the reference's layout}.
 """
@@ -176,11 +176,12 @@ def _acc(grads, name, g):
     grads[name] = g if name not in grads else grads[name] + g
 
 
-def loss_and_grads(model, samples, freeze_btadapter=False):
+def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
     """model: STLLMForCausalLM.  Returns (loss fp32 scalar tensor, loss_mvm or None, grads {reference name: fp32 tensor}).
     On the eva_btadapter_g backbone the reference also trains the `visual_encoder.BTAdapter*` parameters (st_llm.py:257-261): their
     gradient is carried back through llama_proj, the frozen Q-Former and ln_vision into the adapter branch (training_vision.py);
-    freeze_btadapter=True skips that and treats the adapter as frozen."""
+    freeze_btadapter=True skips that and treats the adapter as frozen.  drop_path: the adapter blocks' train-mode stochastic depth as
+    per-sample factors (training_vision.drop_path_factors / btadapter_forward_taped); None = the deterministic step."""
     lmw = model                                  # lm_head owner
     lm = model.model                             # STLLMLlamaModel (LlamaModel + stllm_model)
     sm = lm.stllm_model
@@ -190,7 +191,7 @@ def loss_and_grads(model, samples, freeze_btadapter=False):
     dt = runtime.compute_dtype()
     cfg = lm.config
     D = cfg.hidden_size
-    sm._tape = tape = {"want_vision": train_adapter}
+    sm._tape = tape = {"want_vision": train_adapter, "drop_path": drop_path if train_adapter else None}
     try:
         inputs_embeds, attention_mask, un_e, un_a, labels = sm(samples)
     finally:
@@ -411,9 +412,9 @@ def trainable_state_dict(model):
     return {n: p.detach().clone() for n, p in trainable_parameters(model)}
 
 
-def train_step(model, samples, optimizer, freeze_btadapter=False):
+def train_step(model, samples, optimizer, freeze_btadapter=False, drop_path=None):
     """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1)."""
-    loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter)
+    loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter, drop_path)
     norm = optimizer.step(grads)
     invalidate_packed(model)
     return loss, loss_mvm, norm

@@ -168,9 +168,12 @@ def qformer_backward(bert, tape, d_hq32):
 from .training import linear_bwd   # noqa: E402  (dgrad + wgrad of y = x @ w^T through stllm_gemm on transposed operands)
 
 
-def btadapter_forward_taped(vit, x):
+def btadapter_forward_taped(vit, x, drop=None):
     """EVAVisionTransformer_BTAdapter.forward_flat (models/eva_btadapter.py) keeping what the branch's backward needs.
-    Returns (flat fp32 stream [(B*T)*257, 1408], tape)."""
+    Returns (flat fp32 stream [(B*T)*257, 1408], tape).
+    drop: train-mode stochastic depth of the adapter blocks (DropPath 0.1, eva_btadapter.py:259, 274, 280, 303), one dict per adapter
+    layer {"t": f32 [B*256], "s": f32 [B*T], "o": f32 [B]} of per-sample factors keep / keep_prob (drop_path_factors draws them);
+    None = the deterministic (eval-mode) step."""
     from .models.eva_vit import block_forward
     if x.ndim == 5:
         if x.shape[1] == 3:
@@ -191,7 +194,8 @@ def btadapter_forward_taped(vit, x):
     hd = D // H
     h = vit.embed_flat(x, pk, dt)
     br = None
-    tape = dict(B=B, T=T, layers=[], tb=tb)
+    o_idx = torch.cat([torch.arange(nbr) // (P * T), torch.arange(B)]).to(torch.int32).to(dev) if drop is not None else None
+    tape = dict(B=B, T=T, layers=[], tb=tb, drop=drop, o_idx=o_idx)
     for i, bp_ in enumerate(pk["blocks"]):
         block_forward(h, bp_, N, L, H, dt)
         if i < vit.num_layers - vit.depth:
@@ -221,6 +225,8 @@ def btadapter_forward_taped(vit, x):
         q = rec["t_qkv"]
         rec["t_a"] = hip.attention(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], B=B * P, H=H, Sq=T, Skv=T, D=hd, scale=hd ** -0.5)
         rec["t_pr"] = hip.gemm(rec["t_a"], t_["wproj"], dtype=dt, bias=t_["bproj"])
+        if drop is not None:
+            hip.scale_rows(rec["t_pr"], drop[j]["t"], rows_per_group=T)              # res_temporal = drop_path(attn(...)), per (b p)
         hip.gemm(rec["t_pr"], t_["wfc"], dtype=dt, epilogue=hip.EPI_RESID, bias=t_["bfc"], resid=patches)
         # ---- spatial block ----
         s_ = bt["S"][j]
@@ -230,6 +236,8 @@ def btadapter_forward_taped(vit, x):
         q = rec["s_qkv"]
         rec["s_a"] = hip.attention(q[:, :D], q[:, D:2 * D], q[:, 2 * D:], B=N, H=H, Sq=L, Skv=L, D=hd, scale=hd ** -0.5)
         res = hip.gemm(rec["s_a"], s_["wproj"], dtype=dt, bias=s_["bproj"], out_f32=True)
+        if drop is not None:
+            hip.scale_rows(res, drop[j]["s"], rows_per_group=L)                       # res_spatial = drop_path(attn(...)), per (b t)
         nxt = torch.empty_like(br)
         hip.gather_rows(res, tb["sp_patch_rows"], add=br, idx_add=tb["arange_bpt"], out=nxt[:nbr])
         cls_res = vit._cls_mean(res, tb["sp_cls_rows"], B, T)
@@ -240,6 +248,8 @@ def btadapter_forward_taped(vit, x):
         rec["m_raw"] = hip.gemm(rec["m_hn"], s_["wfc1"], dtype=dt, bias=s_["bfc1"])
         rec["m_g"] = hip.gelu(rec["m_raw"])
         hip.gemm(rec["m_g"], s_["wfc2"], dtype=dt, epilogue=hip.EPI_RESID, bias=s_["bfc2"], resid=br)
+        if drop is not None:
+            hip.scale_rows(br, drop[j]["o"], idx=o_idx)                               # x = drop_path(x): the whole block output, per b
         tape["layers"].append(rec)
     out = hip.gather_rows(br, tb["out_src"], add=h, idx_add=tb["arange_main"], scale=0.5)
     return out, tape
@@ -275,6 +285,9 @@ def btadapter_backward(vit, tape, d_out, prefix="model.stllm_model.visual_encode
     for j in range(vit.depth - 1, -1, -1):
         rec, s_, t_ = tape["layers"][j], bt["S"][j], bt["T"][j]
         sp, tp = f"{prefix}BTAdapter_S.{j}.", f"{prefix}BTAdapter_T.{j}."
+        dj = tape["drop"][j] if tape["drop"] is not None else None
+        if dj is not None:
+            hip.scale_rows(d_br, dj["o"], idx=tape["o_idx"])
         # ---- MLP: br += fc2(gelu(fc1(LN2(br)))) -----------------------------------------------------------------------------
         d16 = hip.cast_rows(d_br, dt)
         d_g, dw = linear_bwd(d16, rec["m_g"], s_["wfc2"], dt)
@@ -289,6 +302,8 @@ def btadapter_backward(vit, tape, d_out, prefix="model.stllm_model.visual_encode
         d_cls = torch.zeros((B, T, D), device=dev, dtype=torch.float32)
         hip.bcast_add_t(d_cls, d_br[nbr:].contiguous(), 1.0 / T)
         hip.scatter_add_rows(d_cls.view(B * T, D), tb["sp_cls_rows"], d_res)
+        if dj is not None:
+            hip.scale_rows(d_res, dj["s"], rows_per_group=L)
         d_res16 = hip.cast_rows(d_res, dt)
         d_hn = _attn_block_bwd(grads, sp, d_res16, rec["s_a"], rec["s_qkv"], rec["s_hn1"], s_["wqkv"], s_["wproj"], N, H, L, D, dt)
         d_sx, grads[sp + "norm1.weight"], grads[sp + "norm1.bias"] = hip.layernorm_bwd(rec["s_x"], s_["n1w"], s_["e1"], d_hn)
@@ -298,6 +313,8 @@ def btadapter_backward(vit, tape, d_out, prefix="model.stllm_model.visual_encode
         d_p16 = hip.cast_rows(d_p, dt)
         d_pr, dw = linear_bwd(d_p16, rec["t_pr"], t_["wfc"], dt)
         grads[tp + "temporal_fc.weight"], grads[tp + "temporal_fc.bias"] = dw, hip.colsum(d_p16)
+        if dj is not None:
+            hip.scale_rows(d_pr, dj["t"], rows_per_group=T)
         d_hn = _attn_block_bwd(grads, tp, d_pr, rec["t_a"], rec["t_qkv"], rec["t_hn"], t_["wqkv"], t_["wproj"], B * P, H, T, D, dt)
         _, grads[tp + "norm1.weight"], grads[tp + "norm1.bias"] = hip.layernorm_bwd(rec["t_in"], t_["n1w"], t_["e1"], d_hn, d_p, accumulate=True)
         # ---- layer input: j > 0: new = gather(h) + previous branch (identity);  j == 0: init_input ------------------------------------
@@ -308,3 +325,13 @@ def btadapter_backward(vit, tape, d_out, prefix="model.stllm_model.visual_encode
     grads[prefix + "BTAdapter_position.weight"] = d_pos
     grads[prefix + "BTAdapter_cls"] = (hip.colsum(d_br[nbr:].contiguous()) * 0.5).view(1, 1, D)   # new[nbr:] = (cls_mean + cls + pos[0]) / 2
     return grads
+
+
+def drop_path_factors(B, T, depth=3, drop_prob=0.1, generator=None, device="cpu", patches=256):
+    """timm.layers.drop_path's per-sample factors for one training step of the adapter (bernoulli(keep) / keep, scale_by_keep) at its
+    three call sites per layer: temporal residual per (b, patch), spatial residual per (b, t), block output per b."""
+    keep = 1.0 - drop_prob
+
+    def draw(n):
+        return (torch.bernoulli(torch.full((n,), keep), generator=generator) / keep).to(torch.float32).to(device)
+    return [dict(t=draw(B * patches), s=draw(B * T), o=draw(B)) for _ in range(depth)]

@@ -317,6 +317,12 @@ def gelu_bwd(x, dy):
     return (dy.float() * (cdf + xf * torch.exp(-0.5 * xf * xf) / math.sqrt(2.0 * math.pi))).to(x.dtype)
 
 
+def scale_rows(x, scale, *, rows_per_group=0, idx=None):
+    g = idx.long() if idx is not None else torch.arange(x.shape[0]) // rows_per_group
+    x.copy_((x.float() * scale.float()[g][:, None]).to(x.dtype))
+    return x
+
+
 def bcast_add_t(dst, src, scale):
     dst += scale * src.unsqueeze(1)
 
@@ -346,7 +352,7 @@ def installed():
     names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
              "cross_entropy_rows", "cast_rows", "preprocess_frames", "transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu",
              "swiglu_bwd", "rope_bwd", "attention_bwd", "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum",
-             "relu_bwd", "gelu", "gelu_bwd", "bcast_add_t", "adamw", "sumsq"]
+             "relu_bwd", "gelu", "gelu_bwd", "scale_rows", "bcast_add_t", "adamw", "sumsq"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

@@ -197,3 +197,36 @@ def test_qformer_backward_to_image_tokens(text):
     assert (hq32.view(n, 32, 768) - out.detach()).abs().max() <= 2e-5 * out.abs().max()
     want = ev.grad.reshape(n * P, 1408)
     assert (d_enc - want).abs().max().item() <= 3e-4 * want.abs().max().item()
+
+
+def test_btadapter_branch_backward_with_stochastic_depth():
+    """training_vision.btadapter_backward with injected DropPath factors at the three call sites of every adapter layer (incl. a
+    sample whose whole block output is dropped): gradients of every BTAdapter* parameter for a random output gradient against
+    autograd over the oracle's btadapter_forward with the same factors (4-block ViT, 3 adapter layers, B = 2, T = 4)."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build
+    from stllm_amd import runtime, training_vision
+    cfg = CFGS["btadapter"]
+    model = build(cfg, vit_depth=4, qf_layers=2, llm_layers=1)
+    vit = model.model.stllm_model.visual_encoder
+    p = "model.stllm_model.visual_encoder."
+    sd = sd_from(shapes.stllm_model_shapes(4, 2, False, cfg["video_input"], False, vit_model=cfg["vit_model"], qf_vocab=32000))
+    x = T("input.video", (2, 4, 3, 224, 224))
+    drop = training_vision.drop_path_factors(2, 4, depth=3, drop_prob=0.3, generator=torch.Generator().manual_seed(5))
+    drop[1]["o"] = torch.tensor([0.0, 1.0 / 0.7])                      # sample 0 loses its whole branch state after layer 1
+    assert any((d["t"] == 0).any() for d in drop) and any((d["s"] == 0).any() for d in drop)
+    names = [n for n in sd if n.startswith(p) and "BTAdapter" in n]
+    for n in names:
+        sd[n].requires_grad_(True)
+    R = T("input.bt_dout", (2 * 4 * 257, 1408), 1.0)
+    with torch.enable_grad():
+        out = O.btadapter_forward(x, sd, p, 3, drop=drop).reshape(-1, 1408)
+        (out * R).sum().backward()
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        got_out, tape = training_vision.btadapter_forward_taped(vit, x, drop)
+        grads = training_vision.btadapter_backward(vit, tape, R)
+    assert (got_out - out.detach()).abs().max() <= 3e-5 * out.abs().max()
+    assert set(grads) == set(names)
+    for n in names:
+        want = sd[n].grad
+        assert (grads[n] - want).abs().max().item() <= 3e-4 * max(want.abs().max().item(), 1e-6), n

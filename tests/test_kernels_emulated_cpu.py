@@ -458,3 +458,16 @@ def test_device_proxy_plumbing_dry_run():
             api.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, d[:, :D], d[:, D:2 * D], d[:, 2 * D:], **kw)
     assert torch.equal(g1, g2) and torch.equal(dx_direct, dx_proxy)
     assert d_direct.abs().max() > 0 and torch.equal(d_direct, d_proxy)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scale_rows(dtype):
+    x = rnd(13, 40, seed=110, dtype=dtype)
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0, 2.5])
+    idx = torch.tensor([0, 1, 2, 3, 3, 2, 1, 0, 0, 1, 2, 3, 1], dtype=torch.int32)
+    w1, w2 = C.scale_rows(x.clone(), sc, rows_per_group=4), C.scale_rows(x.clone(), sc, idx=idx)
+    g1, g2 = x.clone(), x.clone()
+    with _hipemu.emulated() as hip:
+        hip.scale_rows(g1, sc, rows_per_group=4)
+        hip.scale_rows(g2, sc, idx=idx)
+    assert torch.equal(g1, w1) and torch.equal(g2, w2)
