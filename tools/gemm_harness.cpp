@@ -62,6 +62,14 @@ int main(int argc, char** argv) {
       {"sk_k1408", 4096, 4224, 1408, STLLM_EPI_STORE, 0, 0},
       {"dp_k6144", 4096, 4096, 6144, STLLM_EPI_STORE, 0, 0},
       {"sk_k4096", 4096, 4352, 4096, STLLM_EPI_STORE, 0, 0},
+      // training step, 16 clips x 576 tokens = 9216 rows: dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T) with fp32 output
+      {"tr_dgrad_down", 9216, 11008, 4096, STLLM_EPI_STORE, 0, 0},
+      {"tr_dgrad_gu", 9216, 4096, 22016, STLLM_EPI_STORE, 0, 0},
+      {"tr_dgrad_qkv", 9216, 4096, 12288, STLLM_EPI_STORE, 0, 0},
+      {"tr_wgrad_down", 4096, 11008, 9216, STLLM_EPI_STORE, 0, 1},
+      {"tr_wgrad_gu", 22016, 4096, 9216, STLLM_EPI_STORE, 0, 1},
+      {"tr_wgrad_qkv", 12288, 4096, 9216, STLLM_EPI_STORE, 0, 1},
+      {"tr_wgrad_lm", 32000, 4096, 9216, STLLM_EPI_STORE, 0, 1},
   };
   int dev_lds = 0;
   CK(hipDeviceGetAttribute(&dev_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, 0));
