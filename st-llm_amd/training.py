@@ -172,8 +172,14 @@ def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model."):
 
 
 # ---- the whole training forward + backward ------------------------------------------------------------------------------
-def _acc(grads, name, g):
-    grads[name] = g if name not in grads else grads[name] + g
+PHASES = None   # set to a list to collect (phase name, torch.cuda.Event) marks of the next loss_and_grads call (tools/train_bench.py)
+
+
+def _mark(name):
+    if PHASES is not None and torch.cuda.is_available():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        PHASES.append((name, ev))
 
 
 def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
@@ -191,6 +197,7 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
     dt = runtime.compute_dtype()
     cfg = lm.config
     D = cfg.hidden_size
+    _mark("start")
     sm._tape = tape = {"want_vision": train_adapter, "drop_path": drop_path if train_adapter else None}
     try:
         inputs_embeds, attention_mask, un_e, un_a, labels = sm(samples)
@@ -198,7 +205,9 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
         sm._tape = None
     B, S, _ = inputs_embeds.shape
     dev = inputs_embeds.device
+    _mark("vision forward + assembly")
     h32, h16, lt = llama_forward_taped(lm, inputs_embeds, attention_mask)
+    _mark("LLM forward")
     grads = {}
     # ---- shifted CE (st_llm.py:125-135) ---------------------------------------------------------------------------
     Wlm = lmw.lm_weight(dt)                                                  # [Vp, D]
@@ -252,7 +261,9 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
         d_h32 = torch.zeros((B * S, D), device=dev, dtype=torch.float32)
         hip.scatter_add_rows(da_in, rows_a, d_h32)
     # ---- the LLM ----------------------------------------------------------------------------------------------------
+    _mark("lm_head + losses (+ MVM target pass)")
     d_emb, g_llm = llama_backward(lm, lt, d_h16, d_h32)
+    _mark("LLM backward")
     grads.update(g_llm)
     # ---- token-block assembly: gather_rows^T (visual rows | embedding-table rows) -------------------------------------
     d_vis = torch.zeros((tape["vis_rows"], D), device=dev, dtype=torch.float32)
@@ -300,6 +311,7 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
         d_enc = training_vision.qformer_backward(sm.Qformer.bert, tape["qf_tape"], d_hq)
         d_feats, _, _ = hip.layernorm_bwd(tape["feats"], sm.ln_vision.weight, sm.ln_vision.eps, d_enc)
         grads.update(training_vision.btadapter_backward(sm.visual_encoder, tape["bt_tape"], d_feats, p + "visual_encoder."))
+    _mark("assembly / pooling / projector / vision backward")
     return loss, loss_mvm, grads
 
 

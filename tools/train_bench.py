@@ -43,9 +43,12 @@ def main():
         for step in range(a.steps + 1):
             torch.cuda.synchronize()
             t0 = time.time()
+            training.PHASES = []
             loss, loss_mvm, grads = training.loss_and_grads(model, samples)
             torch.cuda.synchronize()
             t1 = time.time()
+            marks, training.PHASES = training.PHASES, None
+            print("   " + "  |  ".join(f"{n}: {a.elapsed_time(b):.1f} ms" for (_, a), (n, b) in zip(marks[:-1], marks[1:])), flush=True)
             norm = opt.step(grads)
             training.invalidate_packed(model)
             torch.cuda.synchronize()
