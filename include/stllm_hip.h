@@ -255,8 +255,8 @@ int stllm_rope_bwd(int dtype, void* d, int64_t ld, const float* cos_t, const flo
 
 /* Gradients of stllm_attention: dq, dk, dv from q, k, v, the forward output o and its gradient dO; same element addressing as
  * stllm_attention for all eight operands; masks as in the forward (causal needs Sq == Skv).  D % 8 == 0, D <= 128.
- * bf16 / f16 with D == 128 and Sq == Skv (the Llama prefill) run on MFMA kernels, everything else (fp32, the Q-Former's 64-wide
- * heads and cross-attention, EVA's 88-wide heads) on the fp32-FMA kernels.
+ * bf16 / f16 run on MFMA kernels (the Llama prefill, the Q-Former's 64-wide self- and cross-attention heads, EVA's 88-wide heads padded
+ * to 96 in LDS), fp32 on fp32-FMA kernels (also for 16-bit operands with STLLM_ATTN_BWD_VALU=1 in the environment).
  * workspace: stllm_attention_bwd_workspace_bytes(B, H, Sq) (log-sum-exp and dO.o per query row). */
 int64_t stllm_attention_bwd_workspace_bytes(int B, int H, int Sq);
 int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,

@@ -368,7 +368,7 @@ __device__ __forceinline__ void store_acc_t(const f32x16* acc, const MPtr& t, in
 
 template <typename T, int DP>
 __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, float* __restrict__ ws, int H,
-                                                                   int S, int D, float scale, int causal, const int32_t* __restrict__ kv_len) {
+                                                                   int S, int Skv, int D, float scale, int causal, const int32_t* __restrict__ kv_len) {
   constexpr int kKS = MC<DP>::KS, kDB = MC<DP>::DB, kCPT = MC<DP>::CPT;
   __shared__ __attribute__((aligned(16))) char k_lds[32 * MC<DP>::RowPitch];
   __shared__ __attribute__((aligned(16))) char v_lds[32 * MC<DP>::RowPitch];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   const int q_blk0 = blockIdx.x * (32 * kNW);
   const int qrow = q_blk0 + wave * 32 + li;                 // this lane's query (column of every accumulator tile)
   const int wave_q_last = q_blk0 + wave * 32 + 31;
-  const int kvlen = kv_len ? min(kv_len[b], S) : S;
+  const int kvlen = kv_len ? min(kv_len[b], Skv) : Skv;
   const int kv_end = causal ? min(kvlen, q_blk0 + 32 * kNW) : kvlen;
   const float scale_log2 = scale * 1.4426950408889634f;
   i32x4 qf[kKS], dof[kKS];
@@ -395,12 +395,12 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
   // ---- sweep 1: log-sum-exp of the scaled scores, log2 domain ------------------------------------------------------------
   float m_run = kNegBig, l_run = 0.0f;
   i32x4 kreg[kCPT], vreg[kCPT];
-  if (kv_end > 0) fetch_tile16<T, DP>(kreg, k, b, h, D, 0, S, tid);
+  if (kv_end > 0) fetch_tile16<T, DP>(kreg, k, b, h, D, 0, Skv, tid);
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();                       // previous tile fully consumed
     put_tile16<DP>(kreg, k_lds, nullptr, tid);
     __syncthreads();
-    if (kv0 + 32 < kv_end) fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, S, tid);
+    if (kv0 + 32 < kv_end) fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, Skv, tid);
     if (causal && kv0 > wave_q_last) continue;
     f32x16 s = tile_nt<T, DP>(k_lds, qf, li, lh);
     float mx = kNegBig;
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
   if (kv_end > 0) {
-    fetch_tile16<T, DP>(kreg, k, b, h, D, 0, S, tid);
-    fetch_tile16<T, DP>(vreg, v, b, h, D, 0, S, tid);
+    fetch_tile16<T, DP>(kreg, k, b, h, D, 0, Skv, tid);
+    fetch_tile16<T, DP>(vreg, v, b, h, D, 0, Skv, tid);
   }
   for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
     __syncthreads();
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
     put_tile16<DP>(vreg, v_lds, nullptr, tid);
     __syncthreads();
     if (kv0 + 32 < kv_end) {
-      fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, S, tid);
-      fetch_tile16<T, DP>(vreg, v, b, h, D, kv0 + 32, S, tid);
+      fetch_tile16<T, DP>(kreg, k, b, h, D, kv0 + 32, Skv, tid);
+      fetch_tile16<T, DP>(vreg, v, b, h, D, kv0 + 32, Skv, tid);
     }
     if (causal && kv0 > wave_q_last) continue;
     f32x16 s = tile_nt<T, DP>(k_lds, qf, li, lh);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dq_mfma_kernel(Ptr q, Ptr k
 
 template <typename T, int DP>
 __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr k, Ptr v, Ptr dO, MPtr dk, MPtr dv, const float* __restrict__ ws,
-                                                                    int H, int S, int D, float scale, int causal,
+                                                                    int H, int S, int Skv, int D, float scale, int causal,
                                                                     const int32_t* __restrict__ kv_len) {
   constexpr int kKS = MC<DP>::KS, kDB = MC<DP>::DB, kCPT = MC<DP>::CPT;
   __shared__ __attribute__((aligned(16))) char q_lds[32 * MC<DP>::RowPitch];
@@ -475,11 +475,11 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
   const int k_blk0 = blockIdx.x * (32 * kNW);
   const int krow = k_blk0 + wave * 32 + li;                  // this lane's key (column of every accumulator tile)
   const int wave_k_first = k_blk0 + wave * 32;
-  const int kvlen = kv_len ? min(kv_len[b], S) : S;
+  const int kvlen = kv_len ? min(kv_len[b], Skv) : Skv;
   const float scale_log2 = scale * 1.4426950408889634f;
   i32x4 kf[kKS], vf[kKS];
-  load_frags<T, DP>(kf, k, b, h, D, krow, S, lh);
-  load_frags<T, DP>(vf, v, b, h, D, krow, S, lh);
+  load_frags<T, DP>(kf, k, b, h, D, krow, Skv, lh);
+  load_frags<T, DP>(vf, v, b, h, D, krow, Skv, lh);
   f32x16 accv[kDB], acck[kDB];
 #pragma unroll
   for (int i = 0; i < kDB; ++i)
@@ -516,26 +516,26 @@ __global__ __launch_bounds__(64 * kNW) void attn_bwd_dkv_mfma_kernel(Ptr q, Ptr 
     tile_tn<T, DP>(accv, dot_lds, s, li, lh);                    // dV^T += dO^T P
     tile_tn<T, DP>(acck, qt_lds, ds, li, lh);                    // dK^T += Q^T dS
   }
-  if (krow < S) {
+  if (krow < Skv) {
     store_acc_t<T, DP>(accv, dv, b, h, D, krow, lh, 1.0f);
     store_acc_t<T, DP>(acck, dk, b, h, D, krow, lh, scale);
   }
 }
 
 template <typename T, int DP>
-int launch_bwd_mfma_dp(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int D, float scale,
-                       int causal, const int32_t* kv_len, hipStream_t st) {
-  const dim3 grid((S + 32 * kNW - 1) / (32 * kNW), H, B), block(64 * kNW);
-  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T, DP>), grid, block, 0, st, q, k, v, o, dO, dq, ws, H, S, D, scale, causal, kv_len);
-  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T, DP>), grid, block, 0, st, q, k, v, dO, dk, dv, ws, H, S, D, scale, causal, kv_len);
+int launch_bwd_mfma_dp(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int Skv, int D,
+                       float scale, int causal, const int32_t* kv_len, hipStream_t st) {
+  const dim3 gq((S + 32 * kNW - 1) / (32 * kNW), H, B), gk((Skv + 32 * kNW - 1) / (32 * kNW), H, B), block(64 * kNW);
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<T, DP>), gq, block, 0, st, q, k, v, o, dO, dq, ws, H, S, Skv, D, scale, causal, kv_len);
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<T, DP>), gk, block, 0, st, q, k, v, dO, dk, dv, ws, H, S, Skv, D, scale, causal, kv_len);
   return STLLM_OK;
 }
 template <typename T>
-int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int D, float scale, int causal,
-                    const int32_t* kv_len, hipStream_t st) {
-  if (D <= 64) return launch_bwd_mfma_dp<T, 64>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
-  if (D <= 96) return launch_bwd_mfma_dp<T, 96>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
-  return launch_bwd_mfma_dp<T, 128>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, D, scale, causal, kv_len, st);
+int launch_bwd_mfma(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, int H, int S, int Skv, int D, float scale,
+                    int causal, const int32_t* kv_len, hipStream_t st) {
+  if (D <= 64) return launch_bwd_mfma_dp<T, 64>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, Skv, D, scale, causal, kv_len, st);
+  if (D <= 96) return launch_bwd_mfma_dp<T, 96>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, Skv, D, scale, causal, kv_len, st);
+  return launch_bwd_mfma_dp<T, 128>(q, k, v, o, dO, dq, dk, dv, ws, B, H, S, Skv, D, scale, causal, kv_len, st);
 }
 
 template <typename T, int DP>
@@ -590,11 +590,11 @@ extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64
   const BwdDims dims{H, Sq, Skv, D, scale, causal, kv_len};
   int rc;
   const char* force = getenv("STLLM_ATTN_BWD_VALU");
-  const bool mfma = !(force && force[0] == '1') && Sq == Skv;      // self-attention (Llama prefill, ViT / adapter blocks, Q-Former)
+  const bool mfma = !(force && force[0] == '1');      // 16-bit operands: MFMA kernels; fp32 always runs the fp32-FMA kernels
   switch (dtype) {
-    case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, D, scale, causal, kv_len, s)
+    case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, Skv, D, scale, causal, kv_len, s)
                                : launch_bwd_dp<bf16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
-    case STLLM_F16: rc = mfma ? launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, D, scale, causal, kv_len, s)
+    case STLLM_F16: rc = mfma ? launch_bwd_mfma<f16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, Skv, D, scale, causal, kv_len, s)
                               : launch_bwd_dp<f16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
     case STLLM_F32: rc = launch_bwd_dp<float>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;
     default: stllm_set_error("stllm_attention_bwd: bad dtype %d", dtype); return STLLM_ERR_BAD_DTYPE;
