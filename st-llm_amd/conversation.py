@@ -5,7 +5,7 @@ GPU (processors.VideoTransform); video decoding, prompt t
 host-side text/media utilities and out of scope."""
 import torch
 
-from . import hip, runtime
+from . import hip
 from .models.st_llm import get_residual_index
 from .processors import VideoTransform, is_raw_frames
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import Embedding, LayerNorm, Linear, Output, _dev
+from .layers import Embedding, LayerNorm, Linear, Output
 
 
 class BertConfig:

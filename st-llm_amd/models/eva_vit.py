@@ -9,7 +9,6 @@ checkpoints load unchanged.  Per block (eva_vit.py:173-180, gamma_1/2 None for e
 
 The residual stream is fp32; GEMM/attention operands are the compute dtype (runtime.compute_dtype()).
 """
-import math
 
 import torch
 import torch.nn as nn

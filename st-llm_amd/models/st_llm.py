@@ -18,7 +18,6 @@ What differs by design (MI355X-first):
 Tokenizers are host-side text utilities: ``llama_tokenizer`` / ``tokenizer`` are the offline IdTokenizer
 unless real HF tokenizer files are supplied.
 """
-import math
 import os
 import re
 
@@ -29,8 +28,8 @@ import torch.nn as nn
 from .. import hip, runtime
 from ..common.registry import registry
 from ..tokenizer import IdTokenizer
-from .blip2 import BaseModel, Blip2Base, disabled_train
-from .layers import LayerNorm, Linear, Output, _dev
+from .blip2 import BaseModel, Blip2Base
+from .layers import LayerNorm, Linear, Output
 from .llama import LlamaConfig, LlamaForCausalLM, LlamaModel
 from .utils import RandomMaskingGenerator
 
