@@ -40,11 +40,22 @@ def build(force=False):
         with open(tu, "w") as fh:
             fh.write(head + text)
         tus.append(tu)
-    cmd = [CLANG, "-x", "c++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-comment",
-           "-I", HERE, "-I", OUT, "-I", CSRC] + tus + [os.path.join(HERE, "p8_stubs.cpp"), os.path.join(CSRC, "error.cpp"), "-o", lib]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    flags = ["-x", "c++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-comment", "-Wno-psabi",
+             "-I", HERE, "-I", OUT, "-I", CSRC]
+    units = tus + [os.path.join(HERE, "p8_stubs.cpp"), os.path.join(CSRC, "error.cpp")]
+
+    def compile_one(src):
+        obj = os.path.join(OUT, os.path.basename(src) + ".o")
+        r = subprocess.run([CLANG] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"emulation build failed for {src}:\n" + r.stderr[-4000:])
+        return obj
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(units))) as ex:       # one clang per translation unit, in parallel
+        objs = list(ex.map(compile_one, units))
+    r = subprocess.run([CLANG, "-shared", "-pthread", "-o", lib] + objs, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("emulation build failed:\n" + r.stderr[-4000:])
+        raise RuntimeError("emulation link failed:\n" + r.stderr[-4000:])
     return lib
 
 
