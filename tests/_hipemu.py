@@ -16,6 +16,7 @@ def _builder():
 
 
 ON_DEVICE = os.environ.get("STLLM_TRAIN_KERNELS_ON_DEVICE") == "1"   # set by tests/test_train_gpu.py for its child process
+DRY_RUN = os.environ.get("STLLM_TRAIN_KERNELS_ON_DEVICE") == "dry"    # the device-mode plumbing (proxy) over the emulated library
 
 
 def available():
@@ -75,6 +76,6 @@ def emulated():
     hip._req = lambda t, dtype=None, what="tensor": t
     hip.gemm_workspace = lambda device: torch.zeros(16, dtype=torch.uint8)
     try:
-        yield hip
+        yield _DeviceProxy(hip, to_device=lambda t: t.detach().clone(), sync=lambda: None) if DRY_RUN else hip
     finally:
         hip._lib, hip._train_bound, hip._stream, hip._req, hip.gemm_workspace = saved
