@@ -217,3 +217,30 @@ def test_data_parallel_llama_training_matches_single_process():
     for rank, _, params in res:
         for n, p in model.named_parameters():
             assert torch.allclose(torch.from_numpy(params[n]), p, rtol=1e-5, atol=1e-6), (rank, n)
+
+
+def test_weight_gradient_unpackers_invert_the_packers():
+    """training.unpack_qkv_grad / unpack_gate_up_grad are the exact inverses of pack.llama_qkv / pack.llama_gate_up (index permutations)"""
+    from stllm_amd import pack, training
+    g = torch.Generator().manual_seed(7)
+    wq, wk, wv = (torch.randn(256, 64, generator=g) for _ in range(3))
+    q, k, v = training.unpack_qkv_grad(pack.llama_qkv(wq, wk, wv, torch.float32, n_heads=2), 2)
+    assert torch.equal(q, wq) and torch.equal(k, wk) and torch.equal(v, wv)
+    wg, wu = torch.randn(96, 40, generator=g), torch.randn(96, 40, generator=g)
+    a, b = training.unpack_gate_up_grad(pack.llama_gate_up(wg, wu, torch.float32))
+    assert torch.equal(a, wg) and torch.equal(b, wu)
+
+
+def test_trainable_state_dict_round_trip():
+    """what a checkpoint holds (train_hf.py:188-203: the parameters that require grad) loads back by name into a fresh model"""
+    from stllm_amd import training
+    a, b = _tiny_lm(), _tiny_lm()
+    with torch.no_grad():
+        for _, p in training.trainable_parameters(a):
+            p.add_(1.0)
+    sd = training.trainable_state_dict(a)
+    assert set(sd) == {n for n, _ in a.named_parameters()}            # a plain Llama: everything is trainable
+    missing, unexpected = b.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
