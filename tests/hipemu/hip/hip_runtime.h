@@ -71,23 +71,26 @@ inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b
 struct emu_block {
   std::barrier<> all;
   std::vector<std::unique_ptr<std::barrier<>>> wave;
-  std::vector<float> xch;
-  std::vector<float> ma, mb;            // MFMA operand exchange: [thread][8]
-  explicit emu_block(int n) : all(n), xch(n), ma(8 * n), mb(8 * n) {
+  // wave collectives exchange through DOUBLE-buffered arrays: every lane of a wave runs the same sequence of collectives, so a
+  // per-thread phase bit selects the buffer and ONE barrier per collective suffices (a buffer is rewritten only two collectives
+  // later, after every lane has passed the barrier of the collective in between, i.e. finished reading it)
+  std::vector<float> xch;               // [2][thread]
+  std::vector<float> ma, mb;            // MFMA operand exchange: [2][thread][8]
+  int n;
+  explicit emu_block(int n_) : all(n_), xch(2 * n_), ma(16 * n_), mb(16 * n_), n(n_) {
     for (int w = 0; w < (n + 63) / 64; ++w) wave.emplace_back(new std::barrier<>(std::min(64, n - 64 * w)));
   }
 };
 inline thread_local emu_block* emu_cur = nullptr;
+inline thread_local int emu_phase = 0;   // toggles on every wave collective of this thread
 inline void __syncthreads() { emu_cur->all.arrive_and_wait(); }
 inline float __shfl_xor(float v, int mask, int width = 64) {
   (void)width;
   const int t = threadIdx.x;
-  auto& bar = *emu_cur->wave[t >> 6];
-  emu_cur->xch[t] = v;
-  bar.arrive_and_wait();
-  const float r = emu_cur->xch[t ^ mask];
-  bar.arrive_and_wait();
-  return r;
+  float* buf = emu_cur->xch.data() + (emu_phase ^= 1) * emu_cur->n;
+  buf[t] = v;
+  emu_cur->wave[t >> 6]->arrive_and_wait();
+  return buf[t ^ mask];
 }
 // LDS-DMA (global_load_lds): every lane copies `n` bytes from its own global address to the wave-uniform LDS base + lane * n
 template <class G, class L> inline void emu_global_load_lds(G g, L l, int n, int off) {
@@ -95,12 +98,11 @@ template <class G, class L> inline void emu_global_load_lds(G g, L l, int n, int
 }
 inline int __any(int pred) {                                  // wave vote
   const int t = threadIdx.x, w0 = t & ~63;
-  auto& bar = *emu_cur->wave[t >> 6];
-  emu_cur->xch[t] = pred ? 1.0f : 0.0f;
-  bar.arrive_and_wait();
+  float* buf = emu_cur->xch.data() + (emu_phase ^= 1) * emu_cur->n;
+  buf[t] = pred ? 1.0f : 0.0f;
+  emu_cur->wave[t >> 6]->arrive_and_wait();
   int r = 0;
-  for (int l = 0; l < 64 && w0 + l < (int)emu_cur->xch.size(); ++l) r |= emu_cur->xch[w0 + l] != 0.0f;
-  bar.arrive_and_wait();
+  for (int l = 0; l < 64 && w0 + l < emu_cur->n; ++l) r |= buf[w0 + l] != 0.0f;
   return r;
 }
 inline void emu_wave_barrier() { emu_cur->wave[threadIdx.x >> 6]->arrive_and_wait(); }
@@ -109,34 +111,35 @@ inline void emu_wave_barrier() { emu_cur->wave[threadIdx.x >> 6]->arrive_and_wai
 // B[KPL*(l/32) .. +KPL)[l%32]; D register j of lane l is D[8*(j/4) + 4*(l/32) + j%4][l%32]  (CDNA3/4 ISA guide, 32x32 layouts).
 template <int KPL, typename VA, typename VC> inline VC emu_mfma_32x32(VA a, VA b, VC c) {
   const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
-  auto& bar = *emu_cur->wave[t >> 6];
-  for (int e = 0; e < KPL; ++e) { emu_cur->ma[8 * t + e] = (float)a[e]; emu_cur->mb[8 * t + e] = (float)b[e]; }
-  bar.arrive_and_wait();
+  const int ph = (emu_phase ^= 1) * 8 * emu_cur->n;
+  float* A = emu_cur->ma.data() + ph;
+  float* B = emu_cur->mb.data() + ph;
+  for (int e = 0; e < KPL; ++e) { A[8 * t + e] = (float)a[e]; B[8 * t + e] = (float)b[e]; }
+  emu_cur->wave[t >> 6]->arrive_and_wait();
   const int n = lane & 31;
   for (int j = 0; j < 16; ++j) {
     const int m = 8 * (j / 4) + 4 * (lane / 32) + (j % 4);
     float acc = c[j];
-    for (int k = 0; k < 2 * KPL; ++k)
-      acc += emu_cur->ma[8 * (w0 + m + 32 * (k / KPL)) + k % KPL] * emu_cur->mb[8 * (w0 + n + 32 * (k / KPL)) + k % KPL];
+    for (int k = 0; k < 2 * KPL; ++k) acc += A[8 * (w0 + m + 32 * (k / KPL)) + k % KPL] * B[8 * (w0 + n + 32 * (k / KPL)) + k % KPL];
     c[j] = acc;
   }
-  bar.arrive_and_wait();
   return c;
 }
 template <typename VC> inline VC emu_mfma_32x32_f32(float a, float b, VC c) {   // 32x32x2: lane l holds A[l%32][l/32], B[l/32][l%32]
   const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
-  auto& bar = *emu_cur->wave[t >> 6];
-  emu_cur->ma[8 * t] = a;
-  emu_cur->mb[8 * t] = b;
-  bar.arrive_and_wait();
+  const int ph = (emu_phase ^= 1) * 8 * emu_cur->n;
+  float* A = emu_cur->ma.data() + ph;
+  float* B = emu_cur->mb.data() + ph;
+  A[8 * t] = a;
+  B[8 * t] = b;
+  emu_cur->wave[t >> 6]->arrive_and_wait();
   const int n = lane & 31;
   for (int j = 0; j < 16; ++j) {
     const int m = 8 * (j / 4) + 4 * (lane / 32) + (j % 4);
     float acc = c[j];
-    for (int k = 0; k < 2; ++k) acc += emu_cur->ma[8 * (w0 + m + 32 * k)] * emu_cur->mb[8 * (w0 + n + 32 * k)];
+    for (int k = 0; k < 2; ++k) acc += A[8 * (w0 + m + 32 * k)] * B[8 * (w0 + n + 32 * k)];
     c[j] = acc;
   }
-  bar.arrive_and_wait();
   return c;
 }
 
@@ -178,6 +181,7 @@ void emu_launch(K kern, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t /*str
             blockDim = block;
             gridDim = grid;
             emu_cur = &blk;
+            emu_phase = 0;
             kern(args...);
             blk.wave[t >> 6]->arrive_and_drop();   // exited lanes / waves no longer take part in barriers (as in hardware)
             blk.all.arrive_and_drop();
