@@ -471,3 +471,20 @@ def test_scale_rows(dtype):
         hip.scale_rows(g1, sc, rows_per_group=4)
         hip.scale_rows(g2, sc, idx=idx)
     assert torch.equal(g1, w1) and torch.equal(g2, w2)
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_emulated_split_kv_decode_attention(dtype):
+    """the one-token decode step's attention (split-KV partial + merge kernels) on a strided KV cache layout == contract"""
+    B, H, D, Skv, ML = 2, 2, 128, 100, 128                       # cache rows [B, ML, 3*H*D]; 100 keys in use
+    HD = H * D
+    cache = rnd(B * ML, 3 * HD, seed=120, dtype=dtype, scale=0.6)
+    row = cache.view(B, ML, 3 * HD)[:, Skv - 1]                  # the new token's fused row (q | k | v)
+    kw = dict(B=B, H=H, Sq=1, Skv=Skv, D=D, scale=D ** -0.5, causal=False, q_strides=(ML * 3 * HD, 3 * HD), k_strides=(ML * 3 * HD, 3 * HD),
+              v_strides=(ML * 3 * HD, 3 * HD))
+    want = C.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
+    with _hipemu.emulated() as hip:
+        got = hip.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
+        assert hip._decode_attn
+    close(got, want, 2 * TOL[dtype], "decode attention")
