@@ -488,3 +488,33 @@ def test_emulated_split_kv_decode_attention(dtype):
         got = hip.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
         assert hip._decode_attn
     close(got, want, 2 * TOL[dtype], "decode attention")
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_model_gpu.py on the device")
+def test_generate_on_emulated_kernels():
+    """The decode surface (`generate(inputs_embeds=...)`: prefill into the KV cache, then one-token steps on the GEMV kernel, the
+    RoPE epilogue at the step's position and the split-KV attention) with every kernel executed from source in the emulator:
+    same greedy and beam-search token ids and first-step logits as the contract backend (1-layer Llama, 1 head x 128, vocab 128, bf16)."""
+    from stllm_amd import runtime, synth
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    model = STLLMForCausalLM(StllmConfig(hidden_size=128, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1,
+                                         vocab_size=128), device="cpu")
+    synth.fill_module_(model, 0, "")
+    emb = rnd(1, 9, 128, seed=130, scale=0.5)
+
+    def run():
+        model.model.repack()
+        model._lm_packed = {}
+        ids = model.generate(inputs_embeds=emb, max_new_tokens=3, eos_token_id=None)
+        beam = model.generate(inputs_embeds=emb, max_new_tokens=3, num_beams=3, eos_token_id=None)    # 3 rows: GEMV with MR = 4, cache re-order
+        logits = model(samples=None, inputs_embeds=emb).logits[:, -1]
+        return (ids, beam), logits
+
+    with runtime.use_dtype("bf16"):
+        with C.installed():
+            want_ids, want_logits = run()
+        with _hipemu.emulated():
+            got_ids, got_logits = run()
+    close(got_logits, want_logits, 2.0 ** -6, "prefill logits")
+    for g, w in zip(got_ids, want_ids):
+        assert torch.equal(g, w), (g, w)
