@@ -513,8 +513,15 @@ def test_generate_on_emulated_kernels():
     with runtime.use_dtype("bf16"):
         with C.installed():
             want_ids, want_logits = run()
-        with _hipemu.emulated():
+            want5 = model.generate(inputs_embeds=emb, max_new_tokens=2, num_beams=5, eos_token_id=None)
+        with _hipemu.emulated() as hip:
             got_ids, got_logits = run()
+            hip.set_option("gemm_gemv", 2)          # demo.py's num_beams = 5 on the staged M <= 8 GEMV (MR = 6)
+            try:
+                got5 = model.generate(inputs_embeds=emb, max_new_tokens=2, num_beams=5, eos_token_id=None)
+                assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel")
+            finally:
+                hip.set_option("gemm_gemv", -1)
     close(got_logits, want_logits, 2.0 ** -6, "prefill logits")
-    for g, w in zip(got_ids, want_ids):
+    for g, w in zip(got_ids + (got5,), want_ids + (want5,)):
         assert torch.equal(g, w), (g, w)
