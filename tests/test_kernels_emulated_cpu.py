@@ -525,3 +525,38 @@ def test_generate_on_emulated_kernels():
     close(got_logits, want_logits, 2.0 ** -6, "prefill logits")
     for g, w in zip(got_ids + (got5,), want_ids + (want5,)):
         assert torch.equal(g, w), (g, w)
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by the model tests on the device")
+def test_small_qformer_forward_and_dgrad_sweep_on_emulated_kernels():
+    """A narrow Q-Former (hidden 128 = 2 heads x 64, 2 layers incl. one with cross-attention, text stream with a key mask, image
+    tokens 128 wide) through the product's host graphs — BertModel.encode, training_vision.qformer_forward_taped / qformer_backward —
+    with every kernel emulated (tile GEMMs with 2-level rows, LayerNorm, self- and cross-attention forward and MFMA backward, GELU)
+    == the same graphs on the contract backend (bf16)."""
+    from stllm_amd import runtime, synth, training_vision
+    from stllm_amd.models.Qformer import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=64, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=16, encoder_width=128)
+    bert = BertModel(cfg, device="cpu")
+    synth.fill_module_(bert, 0, "Qformer.bert.")
+    n, P = 2, 40
+    qtok = rnd(32, 128, seed=140, scale=0.5)
+    enc = rnd(n * P, 128, seed=141, dtype=torch.bfloat16, scale=0.7)
+    ids = torch.tensor([[1, 17, 23, 9, 4], [1, 8, 0, 0, 0]])
+    mask = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 0, 0, 0]])
+    R = rnd(n * 32, 128, seed=142)
+
+    def run():
+        bert.repack()
+        hq32, _, ht32 = bert.encode(qtok, enc, n, ids, mask)
+        hq32_t, _, tape = training_vision.qformer_forward_taped(bert, qtok, enc, n, ids, mask)
+        d_enc = training_vision.qformer_backward(bert, tape, R)
+        return dict(hq=hq32, ht=ht32, hq_taped=hq32_t, d_enc=d_enc)
+
+    with runtime.use_dtype("bf16"):
+        with C.installed():
+            want = run()
+        with _hipemu.emulated():
+            got = run()
+    for k in want:
+        close(got[k], want[k], 2.0 ** -5, k)
