@@ -33,6 +33,8 @@ def build(force=False):
             ty = m.group(1)
             head = DYN.format(type=ty, n=163840 // (4 if ty == "float" else 1))
         text = re.sub(r"extern\s+__shared__", "EMU_DYN_SHARED", text)
+        # the column reductions split the rows over 64 workgroups to fill the chip; 4 keep the emulation cheap (same code path)
+        text = text.replace("constexpr int kColBlocks = 64;", "constexpr int kColBlocks = 4;")
         # inline ISA: a barrier that does not drain the LDS-DMA queue is a plain barrier here; bare waits vanish (copies are synchronous)
         text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\)', "__syncthreads()", text)
         text = re.sub(r'asm volatile\("s_waitcnt [a-z]+cnt\(\d+\)" ::: "memory"\)', "((void)0)", text)

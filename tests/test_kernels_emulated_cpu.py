@@ -213,10 +213,10 @@ def test_llama_training_graph_entirely_on_emulated_kernels():
     model = STLLMForCausalLM(StllmConfig(hidden_size=256, intermediate_size=384, num_hidden_layers=1, num_attention_heads=2,
                                          vocab_size=256), device="cpu")
     synth.fill_module_(model, 0, "")
-    B, S = 2, 40
+    B, S = 2, 34                                      # two 32-row tiles per sequence, ragged
     emb = rnd(B, S, 256, seed=30, scale=0.5)
     att = torch.ones(B, S, dtype=torch.long)
-    att[1, 29:] = 0
+    att[1, 21:] = 0
     labels = torch.randint(0, 256, (B * S,), generator=torch.Generator().manual_seed(31)).to(torch.int32)
     labels[::3] = -100
 
@@ -506,9 +506,8 @@ def test_generate_on_emulated_kernels():
         model.model.repack()
         model._lm_packed = {}
         ids = model.generate(inputs_embeds=emb, max_new_tokens=3, eos_token_id=None)
-        beam = model.generate(inputs_embeds=emb, max_new_tokens=3, num_beams=3, eos_token_id=None)    # 3 rows: GEMV with MR = 4, cache re-order
         logits = model(samples=None, inputs_embeds=emb).logits[:, -1]
-        return (ids, beam), logits
+        return (ids,), logits
 
     with runtime.use_dtype("bf16"):
         with C.installed():
