@@ -110,9 +110,13 @@ int stllm_gemm_workspace_status(const void* workspace, void* stream);
  * for tile_rows = 192 | 256; heavy = 0 plain 16-bit output, 1 fp32 output / residual, 2 GELU.  T = q * 256 + r tiles of
  * tile_rows x 256; the s workgroups of a remainder tile sit on one XCD (s <= 32, 8 * cap >= r, cap = 32 / s). */
 int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
+/* The same for the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc): shape = 34 (192 x 256 tile) | 44 (256 x 256). */
+int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
+ *   "gemm_w4"    = -1 auto (cost model vs the phased kernel) | 0 off | 1 always | 34 / 44 always, 192 x 256 / 256 x 256 tile:
+ *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on | 0 off | 2 up to M = 8: the skinny M <= 4 kernel of the decode regime (st-llm_amd/csrc/gemv.hip); 2 extends
  *                  it to the 5 beams of demo.py's beam search (staged: checked in emulation, not yet timed on the device)
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels

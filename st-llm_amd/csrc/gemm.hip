@@ -817,6 +817,7 @@ static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): 
 static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
 static int g_gemv_mode = -2;  // stllm_set_option("gemm_gemv")
 static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 phased kernel (3 / 4: force 192 / 256 rows)
+static int g_w4_mode = -2;  // env STLLM_GEMM_W4 / stllm_set_option("gemm_w4"): -1 auto, 0 off, 1 one-wave-per-SIMD kernel (34 / 44: force the tile)
 static int sk_choice(const GemmParams& p, int eb) {
   if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
   const int mode = g_sk_mode;
@@ -885,13 +886,29 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   return est < 0.93f * old_us;
 }
 
+// One-wave-per-SIMD kernel (gemm_w4.inc): same eligibility as the phased kernel.  mode 1 / 34 / 44: always (cost model /
+// 192 x 256 / 256 x 256 tile); auto: when its cost model beats the phased kernel's (profiles/r02_w4_probe.md).
+static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_us, bool p8_ok) {
+  if (g_w4_mode == -2) { const char* e = getenv("STLLM_GEMM_W4"); g_w4_mode = e ? atoi(e) : -1; }
+  if (g_w4_mode == 0 || p.ws == nullptr) return false;
+  if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
+  const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape);
+  if (g_w4_mode == 34 || g_w4_mode == 44) { *shape = g_w4_mode; return true; }
+  if (g_w4_mode == 1) return true;
+  // auto: measured on MI355X (profiles/r02_w4_probe.md) the kernel is 2-4 % faster than the phased kernel on whole-tile
+  // rounds and 2-5 % slower wherever a K-split remainder exists (it publishes the full partial tile); no shape of the bench
+  // path is remainder-free, so the automatic choice stays with the phased kernel until the exchange is slimmer
+  (void)est; (void)p8_est_us; (void)p8_ok;
+  return false;
+}
+
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
     static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): 0 = keep M <= 4 on the tile kernels, 2 = GEMV up to M = 8
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
-    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4;   // tests / experiments
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
     if (p.M <= (gemv_mode == 2 ? 8 : 4) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
@@ -899,7 +916,17 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     int miw = 4;
     const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
                     : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;
-    if (a->epilogue != STLLM_EPI_PATCH && p8_wanted(p, heavy, &miw)) {
+    const bool p8_ok = a->epilogue != STLLM_EPI_PATCH && p8_wanted(p, heavy, &miw);
+    if (a->epilogue != STLLM_EPI_PATCH) {
+      int shape = 44, miw2 = 4;
+      const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2);
+      if (w4_wanted(p, heavy, &shape, p8_est, p8_ok)) {
+        const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
+                                                      : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
+        if (rc != STLLM_ERR_UNSUPPORTED) return rc;
+      }
+    }
+    if (p8_ok) {
       const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_p8_launch_bf16(a->epilogue, miw, p, stream)
                                                     : stllm_gemm_p8_launch_f16(a->epilogue, miw, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
@@ -991,6 +1018,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_w4")) { g_w4_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;

@@ -21,7 +21,7 @@ _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
 
 EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
-           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_set_option",
+           "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_gemm_w4_plan", "stllm_set_option",
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
            "stllm_attention_decode"]
 
@@ -86,6 +86,7 @@ def _bind(L, strict=True):
     B("stllm_attention_decode", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
                                  c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p])
     B("stllm_gemm_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
+    B("stllm_gemm_w4_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
     return L
 
 
@@ -158,6 +159,13 @@ def gemm_plan(M, N, K, heavy=0, tile_rows=192):
     """(q, r, s, cap, est_us) of the phased kernel's schedule (host-only, see stllm_hip.h)."""
     out = (c_int * 5)()
     _check(lib().stllm_gemm_plan(M, N, K, heavy, tile_rows, out), "stllm_gemm_plan")
+    return tuple(out)
+
+
+def gemm_w4_plan(M, N, K, heavy=0, shape=34):
+    """(q, r, s, cap, est_us) of the one-wave-per-SIMD kernel's schedule (host-only, see stllm_hip.h)."""
+    out = (c_int * 5)()
+    _check(lib().stllm_gemm_w4_plan(M, N, K, heavy, shape, out), "stllm_gemm_w4_plan")
     return tuple(out)
 
 

@@ -45,6 +45,8 @@ int main(int argc, char** argv) {
   const int only = argc > 2 ? atoi(argv[2]) : -1;
   const int trace = argc > 3 ? atoi(argv[3]) : 0;
   const int p8opt = argc > 4 ? atoi(argv[4]) : 1;   // 1: cost model picks the tile height, 3 / 4: force 192 / 256 rows
+  const int w4opt = argc > 5 ? atoi(argv[5]) : 0;   // 0: test the phased kernel; 1 / 34 / 44: test the one-wave-per-SIMD kernel (gemm_w4)
+  const int baseopt = argc > 6 ? atoi(argv[6]) : 0; // baseline ("old" column): 0 = 128x128 kernels, 1 = phased kernel (cost model)
   std::vector<Case> cases = {
       {"tiny_store", 256, 256, 128, STLLM_EPI_STORE, 0, 0},
       {"edge_store", 300, 384, 192, STLLM_EPI_STORE, 0, 0},
@@ -62,6 +64,9 @@ int main(int argc, char** argv) {
       {"sk_k1408", 4096, 4224, 1408, STLLM_EPI_STORE, 0, 0},
       {"dp_k6144", 4096, 4096, 6144, STLLM_EPI_STORE, 0, 0},
       {"sk_k4096", 4096, 4352, 4096, STLLM_EPI_STORE, 0, 0},
+      {"dp2_192", 3072, 8192, 1408, STLLM_EPI_STORE, 0, 0},       // 512 tiles of 192 x 256: two whole rounds, no remainder
+      {"dp2_192g", 3072, 8192, 1408, STLLM_EPI_STORE, 1, 0},      // ... with the GELU epilogue
+      {"dp1_192", 3072, 4096, 1408, STLLM_EPI_STORE, 0, 0},       // 256 tiles of 192 x 256: one round
       // training step, 16 clips x 576 tokens = 9216 rows: dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T) with fp32 output
       {"tr_dgrad_down", 9216, 11008, 4096, STLLM_EPI_STORE, 0, 0},
       {"tr_dgrad_gu", 9216, 4096, 22016, STLLM_EPI_STORE, 0, 0},
@@ -122,7 +127,8 @@ int main(int argc, char** argv) {
     a.M = M; a.N = N; a.K = K; a.workspace = ws; a.workspace_bytes = ws_bytes;
 
     auto run = [&](int p8, void* out, float* us, const char** kname) -> int {
-      stllm_set_option("gemm_p8", p8 ? p8opt : 0);
+      stllm_set_option("gemm_p8", p8 ? p8opt : baseopt);
+      stllm_set_option("gemm_w4", p8 ? w4opt : 0);
       stllm_set_option("gemm_sk", p8 ? -1 : 0);
       a.out = out;
       CK(hipMemsetAsync(out, 0xff, obytes, st));
