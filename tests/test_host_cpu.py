@@ -62,6 +62,28 @@ def test_phased_gemm_schedule_invariants():
         hip.gemm_plan(576, 4096, 100, 0, 192)                                  # K must be a multiple of 64
 
 
+def test_w4_gemm_schedule_invariants():
+    """Host logic of the one-wave-per-SIMD GEMM (st-llm_amd/csrc/gemm_w4.inc, w4_make_plan): same invariants as the phased kernel."""
+    from stllm_amd import hip
+    shapes_ = [(4112, 4224, 1408), (4112, 6144, 1408), (4112, 1408, 6144), (576, 12288, 4096), (576, 22016, 4096), (576, 4096, 11008),
+               (4096, 4096, 4096), (1, 128, 64), (300, 384, 192), (100000, 256, 64), (3072, 8192, 1408)]
+    for shape, rows in ((34, 192), (44, 256)):
+        for M, N, K in shapes_:
+            for heavy in (0, 1, 2):
+                q, r, s, cap, est = hip.gemm_w4_plan(M, N, K, heavy, shape)
+                tiles = -(-M // rows) * -(-N // 256)
+                assert q * 256 + r == tiles and 0 <= r < 256, (M, N, K, rows, q, r)
+                assert 1 <= s <= 32 and cap == 32 // s and est > 0
+                if r:
+                    assert 8 * cap >= r and s <= K // 64
+                else:
+                    assert s == 1
+    assert hip.gemm_w4_plan(3072, 8192, 1408, 0, 34)[:3] == (2, 0, 1)          # 512 tiles of 192 x 256: two whole rounds
+    assert hip.gemm_w4_plan(4096, 4096, 4096, 0, 44)[:3] == (1, 0, 1)
+    with pytest.raises(RuntimeError):
+        hip.gemm_w4_plan(576, 4096, 4096, 0, 33)
+
+
 def test_hip_path_has_no_cpu_fallback():
     from stllm_amd import hip
     a = torch.zeros(8, 64, dtype=torch.bfloat16)

@@ -336,6 +336,116 @@ def test_gemm_phased_swiglu_rope_rows(hip, miw):
         hip.set_option("gemm_p8", -1)
 
 
+BENCH_SHAPES = [(4112, 6144, 1408, "gelu"), (4112, 1408, 6144, "resid"), (4112, 4224, 1408, "store"), (4112, 1408, 1408, "resid"),
+                (576, 12288, 4096, "store"), (576, 4096, 11008, "resid")]
+
+
+@pytest.mark.parametrize("M,N,K,kind", BENCH_SHAPES)
+def test_gemm_bench_shapes_auto_dispatch(hip, M, N, K, kind):
+    """the exact GEMM shapes bench.py times (T = 16 ViT rows 16 x 257 = 4112, Llama prefill S = 576), through the automatic
+    dispatch (whatever kernel the cost model picks: phased q = 2 rounds + K-split remainder for fc1), against fp64"""
+    dtype = "bf16"
+    a, a64 = rnd("a", (M, K), dtype, 0.5)
+    w, w64 = rnd("w", (N, K), dtype, 0.05)
+    b = T("b", (N,), 0.5)
+    ref = a64 @ w64.t() + b.double()
+    if kind == "gelu":
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU)
+        name = hip.lib().stllm_last_kernel().decode()
+        check(out, O.gelu(ref), OUT_TOL[dtype], f"bench shape gelu [{name}]")
+    elif kind == "store":
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda())
+        name = hip.lib().stllm_last_kernel().decode()
+        check(out, ref, OUT_TOL[dtype], f"bench shape store [{name}]")
+    else:
+        x = T("x", (M, N), 2.0)
+        xd = x.cuda()
+        hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+        name = hip.lib().stllm_last_kernel().decode()
+        check(xd, x.double() + ref, ACC_TOL[dtype], f"bench shape resid [{name}]")
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+
+
+W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7), (2100, 2944, 256), (3072, 2048, 704)]
+
+
+@pytest.mark.parametrize("shape", [34, 44])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", W4_SHAPES)
+def test_gemm_w4(hip, dtype, shape, M, N, K):
+    """one-wave-per-SIMD kernel forced on (192 x 256 and 256 x 256 tiles): whole rounds, remainder-first K-split with the
+    end-of-launch reduction, M / N tails, fp32 / GELU / residual epilogues, epoch flags, determinism."""
+    hip.set_option("gemm_w4", shape)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        a2, a264 = rnd("a_other", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        ref2 = a264 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_w4_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},{shape // 10},{shape % 10},")
+        check(out, ref, ACC_TOL[dtype], "w4 store f32")
+        for rep in range(3):   # alternate operands: a stale partial slab from the previous launch would show up here
+            check(hip.gemm(a2, w, dtype=dtype, bias=b.cuda(), out_f32=True), ref2, ACC_TOL[dtype], f"w4 store f32 (other operand, rep {rep})")
+            o1 = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+            assert torch.equal(o1, out), "w4: not bit-identical across launches"
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "w4 gelu T")
+        check(hip.gemm(a, w, dtype=dtype), a64 @ w64.t(), OUT_TOL[dtype], "w4 store T, no bias")
+        x = T("x", (M, N), 2.0)
+        xd = x.cuda()
+        for rep in range(2):
+            hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+        check(xd, x.double() + 2 * ref, ACC_TOL[dtype], "w4 resid x2")
+        assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+    finally:
+        hip.set_option("gemm_w4", -1)
+
+
+@pytest.mark.parametrize("shape", [34, 44])
+def test_gemm_w4_swiglu_rope_rows(hip, shape):
+    from stllm_amd import pack
+    dtype = "bf16"
+    hip.set_option("gemm_w4", shape)
+    try:
+        M, K, I = 333, 1024, 1024 + 128 * 3
+        a, a64 = rnd("a", (M, K), dtype)
+        wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+        wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+        out = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
+        assert "gemm_w4_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(out, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "w4 swiglu")
+        B, S, H, D = 2, 150, 4, 128
+        a, a64 = rnd("a2", (B * S, K), dtype)
+        wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+        wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+        wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+        cos, sin = pack.rope_tables(S)
+        qkv = hip.gemm(a, pack.llama_qkv(wq, wk, wv, dtype, n_heads=H), dtype=dtype, epilogue=hip.EPI_ROPE,
+                       rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D).double().cpu().view(B, S, 3, H, D)
+        assert "gemm_w4_kernel" in hip.lib().stllm_last_kernel().decode()
+        c, s = O.rope_tables(S, D)
+        q = (a64 @ wq64.t()).view(B, S, H, D).transpose(1, 2)
+        k = (a64 @ wk64.t()).view(B, S, H, D).transpose(1, 2)
+        q = q * c.double() + O._rotate_half(q) * s.double()
+        k = k * c.double() + O._rotate_half(k) * s.double()
+        perm = pack.rope_head_perm(1)
+        check(qkv[:, :, 0].transpose(1, 2), q[..., perm], OUT_TOL[dtype], "w4 q rope")
+        check(qkv[:, :, 1].transpose(1, 2), k[..., perm], OUT_TOL[dtype], "w4 k rope")
+        check(qkv[:, :, 2], (a64 @ wv64.t()).view(B, S, H, D), OUT_TOL[dtype], "w4 v")
+        # 2-level row indexing (Q-Former style row groups)
+        N_, S2, Q, C, Nout = 5, 44, 32, 768, 256
+        buf, buf64 = rnd("buf", (N_ * S2, C), dtype)
+        w, w64 = rnd("w2", (Nout, C), dtype, 0.05)
+        outb = torch.zeros((N_ * S2, Nout), device="cuda", dtype=torch.float32)
+        hip.gemm(buf, w, dtype=dtype, out=outb, out_f32=True, M=N_ * Q, a_rows=(Q, S2 * C), o_rows=(Q, S2 * Nout))
+        assert "gemm_w4_kernel" in hip.lib().stllm_last_kernel().decode()
+        check(outb.view(N_, S2, Nout)[:, :Q].reshape(-1, Nout), buf64.view(N_, S2, C)[:, :Q].reshape(-1, C) @ w64.t(), ACC_TOL[dtype], "w4 query rows")
+        assert float(outb.view(N_, S2, Nout)[:, Q:].abs().max()) == 0.0
+    finally:
+        hip.set_option("gemm_w4", -1)
+
+
 def test_gemm_phased_auto_dispatch(hip):
     """the cost model sends the long-K / few-row-tile prefill shapes to the phased kernel and keeps small problems on
     the 128x128 kernels"""
