@@ -1,22 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — video-tokens/sec through ViT + Q-Former + projector + Vicuna-7B prefill (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3] [--dtype bf16|fp16|fp32] [--no-cpu-baseline]
 
-A "step" = one pass of the hot path over one batch of synthetic input: per GPU one clip of T=16 random
-224x224 frames (already resident in HBM) -> EVA-CLIP-g (39 blocks) -> ln_vision -> Q-Former (12 layers) ->
-llama_proj -> 'all' pooling (512 video tokens) -> token-block assembly (BOS + 7 + 512 + 40 + 16 = 576
-positions) -> Vicuna-7B (32 layers) prefill -> lm_head on all positions -> shifted CE.  Random-init weights
-(stllm_amd.synth), full sizes: BASELINE.json configs[1].  N > 1: weak scaling — N clips; the B*T frames are
-sharded over the ranks (frame-parallel), ONE RCCL all-gather of the visual tokens, clip c prefilled on rank c.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: bench.py starts the N ranks itself (one process per GPU,
+rendezvous on 127.0.0.1); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it uses the
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it is given.  Rank 0 prints ONE JSON line.
 
-Prints ONE JSON line (rank 0).  `value` = total video tokens (B * 512) / step time, inputs resident in HBM.
+A "step" = one pass of the hot path over one batch of synthetic input (frames already resident in HBM):
+frames -> EVA-CLIP-g (39 blocks) -> ln_vision -> Q-Former (12 layers) -> llama_proj -> [N > 1: ONE RCCL all-gather of the
+projected visual tokens] -> pooling -> token-block assembly -> Vicuna-7B (32 layers) prefill -> lm_head (all positions) ->
+shifted CE.  Random-init weights (stllm_amd.synth), full sizes.
+
+  --config c2 (default; BASELINE.json configs[1], the metric's configuration): per GPU one clip of T=16 frames, 'all' pooling
+      (512 video tokens), S = 576.  N > 1 = WEAK scaling: N clips per step; the N*16 frames are split into N contiguous
+      ranges (= one clip per rank), one all-gather, clip c prefilled on rank c.
+  --config c3 (BASELINE.json configs[2]; reference config/instructblipbase_stllm_conversation.yaml:14-15,21): B=4 clips of
+      T=64 frames, text-conditioned Q-Former, global-local 'residual' pooling R=16 (512 video tokens per clip), S ~ 580.
+      STRONG scaling: the same 4 x 64 frames at every N; frames sharded N ways (frame-parallel), one all-gather, clip c
+      prefilled on rank c % N (clip-parallel) — where the north star's ">= 6x at 8 GPUs" lives.
+  --dry-cpu: plumbing check of the multi-rank code path on CPU (gloo, tests/_cpu_backend.py instead of the HIP library,
+      reduced depth): NOT a measurement — used by tests/test_bench_cpu.py.
+
+`value` = video tokens entering the LLM per second, whole job (B * 512 / step time), inputs resident in HBM.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +39,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, MI355X_MICROARCH.md
+ROUND = 2   # profiles/traffic_r{ROUND:02d}.json is the HBM-traffic measurement that belongs to this round's kernels
+
+CONFIGS = {
+    "c2": dict(clips=None, frames=16, scaling="weak",
+               model=dict(video_input="all", qformer_text_input=False, max_txt_len=32)),
+    "c3": dict(clips=4, frames=64, scaling="strong",
+               model=dict(video_input="residual", residual_size=16, qformer_text_input=True, max_txt_len=64)),
+}
 
 
-def build_model(device, args):
+def build_model(device, args, model_cfg=None):
     from stllm_amd import synth
     from stllm_amd.models import st_llm
     from stllm_amd.models.blip2 import Blip2Base
@@ -37,24 +57,32 @@ def build_model(device, args):
     cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False,
                mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2",
                llama_model=dict(num_hidden_layers=args.llm_layers))
+    cfg.update(model_cfg or {})
     model = st_llm.STLLMForCausalLM.from_config(cfg, device=device)
     synth.fill_module_(model, 0, "")
     return model.eval()
 
 
-def make_samples(B, T, device, seed=0):
+def make_samples(B, T, device, seed=0, text=False):
+    """Fixed token ids + seeded frames.  (B=1, T=16, text=False) is also what tests/golden/make_fixtures.py c2_full fed to
+    the reference: do not change it without regenerating tests/golden/c2_full.npz."""
     from stllm_amd import synth
     g = torch.Generator().manual_seed(seed)
     ids = lambda n: " ".join(str(int(x)) for x in torch.randint(3, 32000, (n,), generator=g))
     frames = synth.normal_(torch.empty(B, T, 3, 224, 224, device=device), "input.video", seed, 1.0)
-    return {"image": frames, "instruction_input": [ids(7) + "<ImageHere>" + ids(40) for _ in range(B)],
-            "answer": [ids(15) for _ in range(B)]}  # +eos => 16 answer ids; BOS is prepended by the model
+    if text:   # InstructBLIP-style prompt: the Q-Former sees the question (st_llm.py:456-459); its ids must also exist in BERT's 30523-word table
+        qids = lambda n: " ".join(str(int(x)) for x in torch.randint(3, 30000, (n,), generator=g))
+        instr = [ids(7) + "<ImageHere>" + ids(16) + " Human: " + qids(24) + " ###" for _ in range(B)]
+    else:
+        instr = [ids(7) + "<ImageHere>" + ids(40) for _ in range(B)]
+    return {"image": frames, "instruction_input": instr, "answer": [ids(15) for _ in range(B)]}  # +eos => 16 answer ids
 
 
-def algorithmic_flops(T, S):
-    """2*MAC, unpadded."""
+def algorithmic_flops(T, S, Lt=0, pooled_clip=False):
+    """2*MAC, unpadded; per clip."""
     vit = T * 520.72e9
-    qf = T * 12.75e9 + T * 0.201e9
+    qf_frame = 12.75e9 + (18.30e9 - 12.75e9) * (Lt / 32.0)
+    qf = T * qf_frame + T * 0.201e9
     llm = S * 2 * 32 * (4 * 4096 ** 2 + 3 * 4096 * 11008) + 2 * S * S * 4096 * 32 + 2 * 4096 * 32000 * S
     return vit + qf + llm
 
@@ -93,44 +121,114 @@ def cpu_baseline(T, S, budget_s=25.0):
                       f"extrapolated linearly to T={T}, 39/12/32 layers => {clip_s:.1f} s/clip"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--vit-depth", type=int, default=39)
-    ap.add_argument("--qformer-layers", type=int, default=12)
-    ap.add_argument("--llm-layers", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--vit-streams", type=int, default=1)
-    args = ap.parse_args()
+def parity_vs_fixture(logits, loss, name="c2_full"):
+    """Logits of the TIMED dtype against the reference's own CPU fp32 forward on the same inputs and synthetic weights
+    (tests/golden/<name>.npz, a data fixture made by tests/golden/make_fixtures.py): max-abs error on the stored
+    sub-sampled slice and top-1 agreement over all positions."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    lg = logits[0].float().cpu()
+    if lg.shape[0] != int(g["seq_len"][0]):
+        return None
+    err = float(np.abs(lg[::3, ::499].numpy() - g["logits_slice"]).max())
+    agree = float((lg.argmax(-1).numpy() == g["top_ids"][:, 0]).mean())
+    return {"fixture": f"tests/golden/{name}.npz (reference CPU fp32 forward, same inputs and weights)",
+            "logits_max_abs_err": round(err, 5), "logits_abs_max": round(float(g["logits_stats"][1]), 3),
+            "top1_agreement": round(agree, 4), "loss_err": round(abs(loss - float(g["loss"][0])), 6)}
 
+
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` from THIS round's PMC measurement (tools/pmc_traffic.sh -> profiles/traffic_rNN.json);
+    None when the file is missing, from another round, or holds another kernel (a stale constant is worse than null)."""
+    tp = os.path.join(ROOT, "profiles", f"traffic_r{ROUND:02d}.json")
+    if not os.path.exists(tp):
+        return None
+    d = json.load(open(tp))
+    if d.get("round") != ROUND:
+        return None
+    e = d.get("kernels", {}).get(kernel)
+    return e.get("hbm_bytes_per_launch") if isinstance(e, dict) else None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and forward rank 0's line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(1.0, deadline - time.time())) or rc
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = rc or 124
+    if rc:
+        for p in procs:   # a rank died: do not leave its peers waiting in a collective
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
+    dry = args.dry_cpu
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+    if dry:
+        device = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=device)
     torch.set_grad_enabled(False)
 
+    import contextlib
+    backend = contextlib.nullcontext()
+    if dry:   # TEST-ONLY contract backend (tests/_cpu_backend.py): checks the orchestration, measures nothing
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _cpu_backend
+        backend = _cpu_backend.installed()
+        args.dtype = "fp32"
+        args.no_roofline = args.no_cpu_baseline = True
+    with backend:
+        _run(args, world, rank, device, dry)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(args, world, rank, device, dry):
     from stllm_amd import hip, runtime
     runtime.set_compute_dtype(args.dtype)
-    model = build_model(device, args)
+    conf = CONFIGS[args.config]
+    T = args.frames if args.frames else conf["frames"]
+    if conf["model"].get("residual_size", 0) > T:   # --frames override (debugging / dry runs): keep R <= T
+        conf = dict(conf, model=dict(conf["model"], residual_size=T))
+    model = build_model(device, args, conf["model"])
     sm = model.model.stllm_model
     sm.set_frame_parallel(rank, world)
     sm.visual_encoder.frame_streams = args.vit_streams
-    B, T = world, args.frames
-    samples = make_samples(B, T, device)
-    Lvis = T * 32
+    B = conf["clips"] if conf["clips"] else world
+    text = conf["model"]["qformer_text_input"]
+    samples = make_samples(B, T, device, text=text)
+    R = conf["model"].get("residual_size")
+    Lvis = (R if conf["model"]["video_input"] == "residual" else T) * 32
 
     def step():
         return model(samples=samples)
@@ -138,22 +236,28 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     # ---- warmup (first step also packs the weights); calibration pass finds the dominant GEMM kernel ----
     out = None
     for i in range(max(args.warmup, 1)):
         out = step()
-    torch.cuda.synchronize()
-    S = out.logits.shape[1]
+    sync()
+    own = getattr(sm, "owned_clips", list(range(B))) if world > 1 else list(range(B))
+    S_local = out.logits.shape[1] if out.logits is not None else 0
+    parity = None
+    if rank == 0 and out.logits is not None and args.config == "c2" and world == 1 and not dry:
+        parity = parity_vs_fixture(out.logits, float(out.loss.item()))
     prof = None
+    cal = {}
     if not args.no_roofline:
         # calibration step on EVERY rank (it contains the all-gather collective); only rank 0 times its GEMM launches
         if rank == 0:
             prof = hip.GemmProfiler()
             hip.set_profiler(prof)
         step()
-        torch.cuda.synchronize()
+        sync()
         if rank == 0:
             cal = prof.summary()
             prof.target = max(cal, key=lambda k: cal[k]["total_ms"])
@@ -165,41 +269,71 @@ def main():
         out = step()
     sync()
     dt_s = time.perf_counter() - t0
-    hip.set_profiler(None)
-    if not hip.gemm_workspace_ok(device):   # a split-K exchange gave up waiting for a peer workgroup: the numbers would be meaningless
-        raise RuntimeError(hip.lib().stllm_last_error().decode())
-    t = torch.tensor([dt_s], device=device, dtype=torch.float64)
+    if not dry:
+        hip.set_profiler(None)
+        if not hip.gemm_workspace_ok(device):   # a split-K exchange gave up waiting for a peer workgroup: the numbers would be meaningless
+            raise RuntimeError(hip.lib().stllm_last_error().decode())
+    t = torch.tensor([dt_s, float(S_local)], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_s = float(t.item())
+    dt_s, S = float(t[0].item()), int(t[1].item())
     ms_per_step = dt_s / args.steps * 1e3
     loss = float(out.loss.item()) if out.loss is not None else float("nan")
 
+    # ---- the collective on its own: the all-gather of the projected tokens, same shape, same stream ----
+    ag_us = None
+    if world > 1:
+        from stllm_amd import parallel
+        n_frames = B * T
+        s0, e0 = parallel.frame_range(n_frames, rank, world)
+        local = torch.zeros((e0 - s0, 32, 4096), dtype=torch.float32, device=device)
+        for _ in range(3):
+            parallel.all_gather_frames(local, n_frames, rank, world)
+        sync()
+        t1 = time.perf_counter()
+        reps = 2 if dry else 20
+        for _ in range(reps):
+            parallel.all_gather_frames(local, n_frames, rank, world)
+        sync()
+        ag_us = (time.perf_counter() - t1) / reps * 1e6
+
     if rank == 0:
-        res = {"metric": "video-tokens/sec (ViT+Qformer+LLM-prefill) at T=16, Vicuna-7B", "value": round(B * Lvis / (dt_s / args.steps), 2),
+        Lt = 24 if text else 0
+        flop_clip = algorithmic_flops(T, S, Lt)
+        step_s = dt_s / args.steps
+        par = "single GPU" if world == 1 else (f"frame-parallel x{world} (contiguous frame ranges) + ONE RCCL all-gather of [frames/{world}, 32, 4096] fp32 + "
+                                               f"clip-parallel prefill (clip c on rank c % {world})")
+        names = {"c2": "BASELINE configs[1]", "c3": "BASELINE configs[2]"}
+        res = {"metric": f"video-tokens/sec (ViT+Qformer+LLM-prefill) at T={T}, Vicuna-7B", "value": round(B * Lvis / step_s, 2),
                "unit": "video-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": conf["scaling"], "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic (random 224x224 frames, random-init EVA-CLIP-g + Q-Former + Vicuna-7B, fixed token ids)",
-               "config": {"workload": f"BASELINE configs[1]: B={B} clip(s)/step ({B // world} per GPU), T={T} frames, ViT {args.vit_depth} blocks + "
-                                      f"Q-Former {args.qformer_layers} layers + Llama {args.llm_layers} layers prefill S={S} + lm_head(all positions)",
-                          "global_batch": B, "frames": T, "video_tokens_per_clip": Lvis, "seq_len": S,
-                          "parallelism": "single GPU" if world == 1 else f"frame-parallel x{world} + RCCL all-gather + clip-parallel prefill"},
-               "frames_per_s": round(B * T / (dt_s / args.steps), 2), "loss": round(loss, 5),
-               "algorithmic_tflop_per_step": round(B * algorithmic_flops(T, S) / 1e12, 3),
-               "end_to_end_tflops_per_gpu": round(algorithmic_flops(T, S) / (dt_s / args.steps) / 1e12, 1)}
-        full = (args.vit_depth, args.qformer_layers, args.llm_layers, T) == (39, 12, 32, 16)
+               "config": {"workload": f"{names[args.config]}: B={B} clip(s)/step, T={T} frames, ViT {args.vit_depth} blocks + "
+                                      f"Q-Former {args.qformer_layers} layers ({'text-conditioned, ' if text else ''}{conf['model']['video_input']} pooling) + "
+                                      f"Llama {args.llm_layers} layers prefill S={S} + lm_head(all positions)",
+                          "name": args.config, "global_batch": B, "frames": T, "video_tokens_per_clip": Lvis, "seq_len": S, "parallelism": par},
+               "frames_per_s": round(B * T / step_s, 2), "encoded_tokens_per_s": round(B * T * 32 / step_s, 1), "loss": round(loss, 5),
+               "algorithmic_tflop_per_step": round(B * flop_clip / 1e12, 3),
+               "end_to_end_tflops_per_gpu": round(B * flop_clip / step_s / 1e12 / world, 1)}
+        if world > 1:
+            res["allgather_us"] = round(ag_us, 1)
+            res["allgather_bytes_per_rank"] = (B * T // world) * 32 * 4096 * 4
+            if conf["scaling"] == "weak":
+                res["scaling_note"] = ("c2 at N > 1 is weak scaling (one clip per GPU; each rank's frame range is its own clip, so the all-gather "
+                                       "carries no remote token the prefill needs); the frame-parallel experiment is --config c3 (strong scaling)")
+        if dry:
+            res["data"] = "DRY RUN on CPU (gloo + tests/_cpu_backend.py): orchestration check, NOT a measurement"
+        full = (args.vit_depth, args.qformer_layers, args.llm_layers, T) == (39, 12, 32, conf["frames"])
         if not full:
             res["config"]["workload"] += "  [REDUCED — not the BASELINE config; for debugging only]"
+        if parity is not None:
+            res["parity"] = dict(parity, dtype=args.dtype)
         if prof is not None and prof.records:
             s = prof.summary()[prof.target]
             avg_ms = s["total_ms"] / s["launches"]
             ach = s["flops"] / (s["total_ms"] * 1e-3) / 1e12
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tp):
-                traffic = json.load(open(tp)).get(prof.target)
             res["roofline"] = {"bound": "mfma", "kernel": prof.target, "achieved": round(ach, 1), "peak": MFMA_PEAK[args.dtype],
-                               "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK[args.dtype], 4), "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK[args.dtype], 4), "traffic": load_traffic(prof.target),
                                "launches_timed": s["launches"], "avg_launch_ms": round(avg_ms, 5),
                                "algorithmic_gflop_per_launch": round(s["flops"] / s["launches"] / 1e9, 2),
                                "all_gemm_kernels_one_step": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
@@ -208,9 +342,27 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0, N=1 only
             res["cpu_baseline"] = cpu_baseline(T, S)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--frames", type=int, default=0, help="override the config's frames per clip (debugging)")
+    ap.add_argument("--vit-depth", type=int, default=39)
+    ap.add_argument("--qformer-layers", type=int, default=12)
+    ap.add_argument("--llm-layers", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--vit-streams", type=int, default=1)
+    ap.add_argument("--dry-cpu", action="store_true", help="run the rank logic on CPU (gloo, contract backend): plumbing check only")
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

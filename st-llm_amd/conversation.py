@@ -72,10 +72,14 @@ class Chat:
 
     def answer(self, img_list, question_ids, max_new_tokens=300, num_beams=1, min_length=1, top_p=0.9,
                repetition_penalty=1.0, length_penalty=1, temperature=1.0, max_length=2000, do_sample=False,
-               stopping_criteria=None, **kw):
+               stopping_criteria=None, instruction=False, **kw):
         """conversation.py:213-253: keep the last `max_length - max_new_tokens` embeddings, generate with the reference's
-        knobs (demo.py: num_beams=5, do_sample=False), drop a leading <unk> (0) / <s> (1) token."""
+        knobs (demo.py: num_beams=5, do_sample=False), drop a leading <unk> (0) / <s> (1) token.  This entry point is the
+        `get_context_emb_sim` path (no conv.instruction: video tokens + question), for which the reference OVERRIDES
+        repetition_penalty with 1.5 (conversation.py:219-220) whatever the caller passed; instruction=True keeps the argument."""
         embs, att = self.get_context_emb_ids(img_list, question_ids)
+        if not instruction:
+            repetition_penalty = 1.5
         begin = max(0, embs.shape[1] - (max_length - max_new_tokens))
         embs = embs[:, begin:]
         if stopping_criteria is None:
@@ -83,6 +87,7 @@ class Chat:
         out = self.LLM.generate(inputs_embeds=embs, max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria,
                                 num_beams=num_beams, do_sample=do_sample, min_length=min_length, top_p=top_p,
                                 repetition_penalty=repetition_penalty, length_penalty=length_penalty, temperature=temperature, **kw)
+        hip.gemm_workspace_check(embs.device, wait=True) if embs.is_cuda else None   # generate() synchronised on every token anyway
         tok = out[0]
         if tok.numel() and int(tok[0]) == 0:   # conversation.py:246-249
             tok = tok[1:]

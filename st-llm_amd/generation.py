@@ -150,6 +150,7 @@ def generate(lm_wrapper, inputs_embeds, max_new_tokens=16, num_beams=1, do_sampl
             if unfinished.max() == 0 or _stop(stopping_criteria, ids, scores) or ids.shape[1] >= max_new_tokens:
                 break
             st.advance(nxt)
+        _check_exchanges(dev)
         return ids
 
     if do_sample:
@@ -213,4 +214,13 @@ def generate(lm_wrapper, inputs_embeds, max_new_tokens=16, num_beams=1, do_sampl
         res[b, :len(o)] = o
         if len(o) < sent_max:
             res[b, len(o)] = eos_token_id
+    _check_exchanges(dev)
     return res
+
+
+def _check_exchanges(dev):
+    """every token was read back on the host, so the stream is idle: a timed-out split-K exchange anywhere in this generate()
+    call must not come back as plausible-looking ids"""
+    if torch.device(dev).type == "cuda":
+        from . import hip
+        hip.gemm_workspace_check(dev, wait=True)

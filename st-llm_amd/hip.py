@@ -124,16 +124,21 @@ def _req(t, dtype=None, what="tensor"):
     return t
 
 
-_workspaces = {}
+_workspaces = {}   # (device index, stream handle) -> workspace
+_ws_probes = {}    # (device index, stream handle) -> (pinned int32[1], event): the error word as of the previous check
+_ERR_WORD_BYTE = 1000 * 4   # kSkErrWord of csrc/gemm_common.h
 
 
 def gemm_workspace(device):
-    """Per-device scratch of the stream-K GEMM (flags + fp32 partial slabs), zeroed once at allocation.
-    One buffer per device: all GEMM launches of this process go to torch's current stream in order."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Scratch of the split-K GEMMs (flags + fp32 partial slabs, 64 MiB), zeroed once at allocation.  The kernels that use it
+    assume the launches sharing a workspace are ordered (stllm_hip.h: "private to the launch stream"), so there is ONE PER
+    (device, stream): a GEMM issued from a second torch stream — e.g. next to an RCCL collective — gets its own flags and slabs
+    instead of racing the first stream's exchanges."""
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{key}")
+        ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{dev}")
         _workspaces[key] = ws
     return ws
 
@@ -171,11 +176,43 @@ def gemm_w4_plan(M, N, K, heavy=0, shape=34):
 
 def gemm_workspace_ok(device=None):
     """Synchronises and returns True when no split-K GEMM exchange on this device ever timed out (see stllm_hip.h)."""
-    key = torch.cuda.current_device() if device is None else torch.device(device).index
-    ws = _workspaces.get(key)
-    if ws is None:
-        return True
-    return int(lib().stllm_gemm_workspace_status(_p(ws), _stream())) == 0
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    ok = True
+    for (d, _), ws in list(_workspaces.items()):
+        if d == dev:
+            ok = ok and int(lib().stllm_gemm_workspace_status(_p(ws), _stream())) == 0
+    return ok
+
+
+def gemm_workspace_check(device=None, wait=False):
+    """Raise if a split-K exchange of an earlier GEMM on `device` gave up waiting for a peer workgroup (its output is invalid;
+    the kernels poll with a bound instead of hanging the GPU, e.g. when another process keeps some CUs busy).
+
+    wait=True synchronises (end of generate(), of an optimizer step: the host waits there anyway).  wait=False costs no
+    synchronisation: it looks at the copy of the error word that the PREVIOUS call enqueued (if that copy has landed) and
+    enqueues a fresh one behind the work submitted so far — a forward() that went wrong is reported by the next call."""
+    if not torch.cuda.is_available():
+        return
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if wait:
+        if not gemm_workspace_ok(dev):
+            raise RuntimeError(lib().stllm_last_error().decode())
+        return
+    for key, ws in list(_workspaces.items()):
+        if key[0] != dev:
+            continue
+        probe = _ws_probes.get(key)
+        if probe is not None and probe[1].query():
+            if int(probe[0][0]) != 0:
+                raise RuntimeError(f"stllm_gemm: a split-K workgroup timed out waiting for a peer (flags {int(probe[0][0]):#x}): the results "
+                                   "of that launch — and of everything computed from them — are invalid")
+            probe = None
+        if probe is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host.copy_(ws[_ERR_WORD_BYTE: _ERR_WORD_BYTE + 4].view(torch.int32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _ws_probes[key] = (host, ev)
 
 
 class GemmProfiler:

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import Embedding, LayerNorm, Linear, Output
+from .layers import Embedding, LayerNorm, Linear, Output, params_fingerprint
 
 
 class BertConfig:
@@ -136,9 +136,12 @@ class BertModel(nn.Module):
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        if dt not in self._packed:
-            self._packed = {dt: [l.pack(dt) for l in self.encoder.layer]}
-        return self._packed[dt]
+        fp = params_fingerprint(self.encoder.layer.parameters())
+        hit = self._packed.get(dt)
+        if hit is None or hit[0] != fp:
+            hit = (fp, [l.pack(dt) for l in self.encoder.layer])
+            self._packed = {dt: hit}
+        return hit[1]
 
     def repack(self):
         self._packed = {}

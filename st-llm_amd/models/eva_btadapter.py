@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from .. import hip, pack, runtime
 from .eva_vit import Attention, Block, VisionTransformer, block_forward
-from .layers import Embedding, LayerNorm, Linear, _dev
+from .layers import Embedding, LayerNorm, Linear, _dev, params_fingerprint
 
 
 class BTAdapter_Spatial(Block):
@@ -69,9 +69,12 @@ class EVAVisionTransformer_BTAdapter(VisionTransformer):
         self._bt_packed = {}
 
     def pack_bt(self, dt):
-        if dt not in self._bt_packed:
-            self._bt_packed = {dt: dict(S=[m.pack(dt) for m in self.BTAdapter_S], T=[m.pack(dt) for m in self.BTAdapter_T])}
-        return self._bt_packed[dt]
+        fp = params_fingerprint([*self.BTAdapter_S.parameters(), *self.BTAdapter_T.parameters()])
+        hit = self._bt_packed.get(dt)
+        if hit is None or hit[0] != fp:
+            hit = (fp, dict(S=[m.pack(dt) for m in self.BTAdapter_S], T=[m.pack(dt) for m in self.BTAdapter_T]))
+            self._bt_packed = {dt: hit}
+        return hit[1]
 
     # ---- index tables (host, cached per (B, T)) -------------------------------------------------------
     def _tables(self, B, T, dev):

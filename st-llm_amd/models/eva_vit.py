@@ -10,11 +10,13 @@ checkpoints load unchanged.  Per block (eva_vit.py:173-180, gamma_1/2 None for e
 The residual stream is fp32; GEMM/attention operands are the compute dtype (runtime.compute_dtype()).
 """
 
+import math
+
 import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import LayerNorm, Linear, _dev
+from .layers import LayerNorm, Linear, _dev, params_fingerprint
 
 
 class Attention(nn.Module):
@@ -103,20 +105,24 @@ class VisionTransformer(nn.Module):
     # -- packing ---------------------------------------------------------------------------------
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        if dt not in self._packed:
-            self._packed = {dt: dict(
+        fp = params_fingerprint([self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.pos_embed, self.cls_token, *self.blocks.parameters()])
+        hit = self._packed.get(dt)
+        if hit is None or hit[0] != fp:
+            hit = (fp, dict(
                 wpatch=pack.patch_weight(self.patch_embed.proj.weight, dt), bpatch=pack.f32(self.patch_embed.proj.bias),
                 pos=self.pos_embed.detach().view(-1, self.embed_dim).float().contiguous(),
                 cls=self.cls_token.detach().view(-1).float().contiguous(),
-                blocks=[b.pack(dt) for b in self.blocks])}
-        return self._packed[dt]
+                blocks=[b.pack(dt) for b in self.blocks]))
+            self._packed = {dt: hit}
+        return hit[1]
 
     def repack(self):
         self._packed = {}
 
-    def _load_from_state_dict(self, *a, **k):
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
         self._packed = {}
-        return super()._load_from_state_dict(*a, **k)
+        interpolate_pos_embed(self, state_dict, prefix + "pos_embed")   # eva_vit.py:435: before the tensors are copied in
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     # -- forward ---------------------------------------------------------------------------------
     def embed_flat(self, x, pk, dt, out=None):
@@ -175,6 +181,44 @@ class VisionTransformer(nn.Module):
 
     def get_num_layers(self):
         return len(self.blocks)
+
+
+def _bicubic_matrix(n_out, n_in):
+    """[n_out, n_in] weights of torch's bicubic resampling along one axis (align_corners=False, cubic-convolution A = -0.75,
+    border taps clamped): out = W @ in.  The 2-D resample is separable: W @ P @ W^T."""
+    A = -0.75
+    scale = n_in / n_out
+    W = torch.zeros(n_out, n_in, dtype=torch.float64)
+    for o in range(n_out):
+        src = (o + 0.5) * scale - 0.5
+        x0 = math.floor(src)
+        t = src - x0
+        coef = (((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A,
+                ((A + 2) * t - (A + 3)) * t * t + 1,
+                ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1,
+                ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A)
+        for k, c in enumerate(coef):
+            W[o, min(max(x0 - 1 + k, 0), n_in - 1)] += c
+    return W
+
+
+def interpolate_pos_embed(model, checkpoint_model, key="pos_embed"):
+    """eva_vit.py:373-394: a checkpoint whose position table belongs to another input resolution is resampled (bicubic, class
+    token kept) to this model's patch grid, in place in `checkpoint_model` — host-side, once, at load time."""
+    if key not in checkpoint_model:
+        return
+    ck = checkpoint_model[key].float()
+    D = ck.shape[-1]
+    num_patches = model.patch_embed.num_patches
+    extra = model.pos_embed.shape[-2] - num_patches
+    orig = int((ck.shape[-2] - extra) ** 0.5)
+    new = int(num_patches ** 0.5)
+    if orig == new:
+        return
+    W = _bicubic_matrix(new, orig)
+    grid = ck[:, extra:].reshape(-1, orig, orig, D).double()
+    out = torch.einsum("oi,bijd,pj->bopd", W, grid, W).reshape(ck.shape[0], new * new, D).float()
+    checkpoint_model[key] = torch.cat((ck[:, :extra], out), dim=1)
 
 
 def create_eva_vit_g(img_size=224, drop_path_rate=0.4, use_checkpoint=False, precision="fp16", depth=39, device=None):

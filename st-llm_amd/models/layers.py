@@ -14,6 +14,17 @@ def _dev(device):
     return device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
 
 
+def params_fingerprint(params):
+    """Cheap identity of a set of master parameters for the packed-weight caches: in-place edits bump `_version`, `.to(device)`
+    / re-assignment changes `data_ptr()`.  (Kernels that write through raw pointers — the optimizer — do neither: training calls
+    repack() explicitly, stllm_amd.training.invalidate_packed.)"""
+    v = a = 0
+    for p in params:
+        v += p._version
+        a ^= p.data_ptr()
+    return (v, a)
+
+
 class Linear(nn.Module):
     """nn.Linear-named holder.  ``forward`` is the generic (unfused) path: y = x @ W^T + b in the current
     compute dtype, fp32 in / fp32 out."""

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import Embedding, Linear, Output, RMSNorm
+from .layers import Embedding, Linear, Output, RMSNorm, params_fingerprint
 
 
 class LlamaConfig:
@@ -98,10 +98,13 @@ class LlamaModel(nn.Module):
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        if dt not in self._packed:
+        fp = params_fingerprint(self.layers.parameters())   # a stale packed copy after p.data.copy_ / .to(device) would run silently
+        hit = self._packed.get(dt)
+        if hit is None or hit[0] != fp:
             self._packed = {}  # one packed copy at a time (13.5 GB at 7B)
-            self._packed[dt] = [l.pack(dt, self.config.num_attention_heads) for l in self.layers]
-        return self._packed[dt]
+            hit = (fp, [l.pack(dt, self.config.num_attention_heads) for l in self.layers])
+            self._packed[dt] = hit
+        return hit[1]
 
     def repack(self):
         self._packed = {}

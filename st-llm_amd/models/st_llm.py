@@ -90,15 +90,22 @@ class STLLMModel(Blip2Base):
             self.Qformer.resize_token_embeddings(len(self.tokenizer))
         self.Qformer.cls = None
         self.llama_tokenizer = IdTokenizer(pad_token_id=0, bos_token_id=1, eos_token_id=2, vocab_size=32000)
+        if qformer_text_input:  # st_llm.py:306-310: '[PAD]' becomes token 32000 (the LLM's tables grow in initialize_vision_modules)
+            self.llama_tokenizer.add_special_tokens({"pad_token": "[PAD]"})
+            for k in ("bos_token", "eos_token", "unk_token"):
+                self.llama_tokenizer.add_special_tokens({k: "</s>"})
+        else:
+            self.llama_tokenizer.pad_token = "$$"
         self.llama_proj = Linear(self.Qformer.config.hidden_size, 4096, device=device)
         self.max_txt_len, self.end_sym = max_txt_len, end_sym
         self.embed_tokens = None  # set by STLLMLlamaModel.initialize_vision_modules (st_llm.py:54)
         self.frame_parallel = None  # (rank, world, group): see stllm_amd.parallel
 
     def set_frame_parallel(self, rank, world, group=None):
-        """Shard the per-frame encode over `world` GPUs (one all-gather of visual tokens) and the prefill by clip."""
-        if world > 1 and self.vit_model != "eva_clip_g":
-            raise NotImplementedError("BT-Adapter couples the frames of a clip (temporal attention): shard by clip instead")
+        """Shard the work of a batch over `world` GPUs.  eva_clip_g: the per-frame encode is split into contiguous frame
+        ranges (one all-gather of visual tokens), the prefill goes by clip.  BT-Adapter backbone: its temporal attention and
+        CLS averaging couple the T frames of a clip (eva_btadapter.py:162-169, 189-190), so the unit of work is the whole
+        clip — rank r encodes AND prefills the clips c with c % world == r, no collective (SURVEY.md §8e "shard by clip")."""
         self.frame_parallel = (rank, world, group) if world > 1 else None
 
     # ------------------------------------------------------------------------------------------
@@ -118,7 +125,7 @@ class STLLMModel(Blip2Base):
         T = image.shape[1]
         infer = image.dim() == 4
         use_image = True if T == 1 or infer else False
-        if self.frame_parallel is not None and not infer:
+        if self.frame_parallel is not None and not infer and self.vit_model == "eva_clip_g":
             from .. import parallel
             rank, world, group = self.frame_parallel
             frames = image.reshape((-1,) + tuple(image.shape[2:]))
@@ -272,13 +279,31 @@ class STLLMModel(Blip2Base):
             qtext = [it.split("Human: ")[1].split(" ###")[0] for it in instruction]
         else:
             qtext = None
+        clip_sharded = False
+        if self.frame_parallel is not None and self.vit_model != "eva_clip_g" and image.dim() == 5:
+            # BT-Adapter: clip-parallel from the first kernel on — this rank's clips only, then the single-GPU path
+            from .. import parallel
+            rank, world, _ = self.frame_parallel
+            own = parallel.clips_of_rank(image.shape[0], rank, world)
+            self.owned_clips = own
+            if not own:
+                return None
+            image = image[own].contiguous()
+            if instruction is not None and not isinstance(instruction, str):
+                instruction = [instruction[c] for c in own]
+            if qtext is not None:
+                qtext = [qtext[c] for c in own]
+            samples = dict(samples, answer=[samples["answer"][c] for c in own])
+            if "mask" in samples and samples["mask"] is not None:
+                samples["mask"] = torch.as_tensor(samples["mask"])[own]
+            clip_sharded = True
         img_embeds, atts_img, use_image = self.encode_img(image, qtext)
         if not use_image:
             img_embeds = self.pool_video(img_embeds)
         elif img_embeds.dim() == 3:
             img_embeds = img_embeds.unsqueeze(1)
         answers_txt = list(samples["answer"])
-        if self.frame_parallel is not None and not use_image:
+        if self.frame_parallel is not None and not use_image and not clip_sharded:
             # clip-parallel prefill: this rank continues with the clips it owns (clip c -> rank c % world)
             from .. import parallel
             rank, world, _ = self.frame_parallel
@@ -348,12 +373,35 @@ class STLLMModel(Blip2Base):
         return model
 
 
+def _resized_rows(w, n, name):
+    """[old, D] -> [n, D]: the first min(old, n) rows are kept, new rows are drawn like HF's _init_weights (normal, std 0.02)"""
+    old = w.shape[0]
+    if old == n:
+        return w
+    new = torch.empty((n, w.shape[1]), dtype=w.dtype, device=w.device)
+    k = min(old, n)
+    new[:k] = w.data[:k]
+    if n > old:
+        g = torch.Generator().manual_seed(20230911 + old)
+        new[old:] = (torch.randn((n - old, w.shape[1]), generator=g) * 0.02).to(new.device, new.dtype)
+    return nn.Parameter(new, requires_grad=w.requires_grad)
+
+
 class STLLMLlamaModel(LlamaModel):
     config_class = StllmConfig
 
     def initialize_vision_modules(self, cfg, device=None):
         self.stllm_model = STLLMModel.from_config(cfg, device=device)
+        if cfg.get("qformer_text_input", False):   # st_llm.py:52-53
+            self.resize_token_embeddings(len(self.stllm_model.llama_tokenizer))
         self.stllm_model.embed_tokens = self.embed_tokens  # shared module (st_llm.py:54)
+
+    def resize_token_embeddings(self, n):
+        """HF PreTrainedModel.resize_token_embeddings for the input table: old rows kept, new rows ~ N(0, initializer_range)
+        from a fixed generator; config.vocab_size follows (the outer model then grows lm_head to it, st_llm.py:180-181)."""
+        self.embed_tokens.weight = _resized_rows(self.embed_tokens.weight, n, "model.embed_tokens.weight")
+        self.config.vocab_size = n
+        return self.embed_tokens
 
     def forward(self, samples=None, inputs_embeds=None, **kwargs):
         if samples is None:
@@ -409,6 +457,14 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
     def get_model(self):
         return self.model
 
+    def resize_token_embeddings(self, n):
+        """st_llm.py:180-181 (`model.resize_token_embeddings(model.config.vocab_size)`): both tables to n rows."""
+        self.model.resize_token_embeddings(n)
+        self.lm_head.weight = _resized_rows(self.lm_head.weight, n, "lm_head.weight")
+        self.vocab_size = self.config.vocab_size = n
+        self._lm_packed = {}
+        return self.model.embed_tokens
+
     def forward(self, samples=None, inputs_embeds=None, **kwargs):
         if samples is None:  # plain causal-LM forward used by generate() (st_llm.py:118-119)
             kwargs.pop("labels", None)
@@ -417,7 +473,9 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
             h16 = out._h16
             if h16.shape[0] != B * S:   # decode steps return the compute-dtype hidden of the LAST token only
                 S = h16.shape[0] // B
-            return Output(loss=None, logits=self.logits_from(h16, B, S), past_key_values=out.past_key_values,
+            logits = self.logits_from(h16, B, S)
+            hip.gemm_workspace_check(logits.device) if logits.is_cuda else None   # non-blocking: reports a timed-out split-K exchange of the PREVIOUS call
+            return Output(loss=None, logits=logits, past_key_values=out.past_key_values,
                           hidden_states=out.hidden_states, attentions=None)
         outputs, loss_pretrain, labels = self.model(samples)
         if outputs is None:
@@ -432,6 +490,7 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
             loss = rows.sum() / (shift != -100).sum().clamp(min=1)
         if loss_pretrain is not None:
             loss = loss + loss_pretrain
+        hip.gemm_workspace_check(logits.device) if logits.is_cuda else None   # non-blocking (see hip.gemm_workspace_check)
         return Output(loss=loss, logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
 
     @torch.no_grad()
@@ -486,6 +545,8 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
         if sd:
             model.load_state_dict(sd, strict=False)
         model.get_model().initialize_vision_modules(cfg, device=device)
+        if cfg.get("qformer_text_input", False):   # st_llm.py:180-181: lm_head follows the input table (32001 rows with '[PAD]')
+            model.resize_token_embeddings(model.config.vocab_size)
         ckpt_path = cfg.get("ckpt", "")
         if ckpt_path and os.path.exists(ckpt_path):
             ckpt = cls.get_state_dict(ckpt_path) if os.path.isdir(ckpt_path) else torch.load(ckpt_path, map_location="cpu")
@@ -493,5 +554,10 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
             if "llm_proj.weight" in ckpt:
                 ckpt["llama_proj.weight"] = ckpt.pop("llm_proj.weight")
                 ckpt["llama_proj.bias"] = ckpt.pop("llm_proj.bias")
+            rows = ckpt.get("model.embed_tokens.weight")
+            if rows is not None and rows.shape[0] != model.config.vocab_size:
+                # a checkpoint trained with a different vocabulary (e.g. saved by a tokenizer without '[PAD]'): strict=False does
+                # not skip shape mismatches, so follow the checkpoint instead of failing in load_state_dict
+                model.resize_token_embeddings(rows.shape[0])
             model.load_state_dict(ckpt, strict=False)
         return model

@@ -12,6 +12,12 @@ import torch
 
 
 class IdTokenizer:
+    # True: add_special_tokens({'pad_token': '[PAD]'}) behaves like HF's LlamaTokenizer — the new token gets the id
+    # len(tokenizer) and the vocabulary grows by one (Vicuna: id 32000, 32001 words), which is what the reference's
+    # InstructBLIP-style models are trained with (st_llm.py:306-310, :52-53, :180-181).  False: a no-op, like the fake tokenizer
+    # the golden fixtures were generated with (tests/golden/ref_shim.py) — the fixture-replay tests switch it off.
+    hf_special_tokens = True
+
     def __init__(self, pad_token_id=0, bos_token_id=1, eos_token_id=2, vocab_size=32000):
         self.pad_token_id, self.bos_token_id, self.eos_token_id = pad_token_id, bos_token_id, eos_token_id
         self.eos_token = f" {eos_token_id}"
@@ -23,7 +29,14 @@ class IdTokenizer:
         return self.vocab_size
 
     def add_special_tokens(self, d):
-        return 0
+        """HF semantics for the one token the reference adds that is not in the vocabulary yet ('[PAD]'); '</s>' (bos / eos /
+        unk in st_llm.py:308-310) already has an id.  Returns the number of tokens added."""
+        if not self.hf_special_tokens or "pad_token" not in d or self.pad_token is not None:
+            return 0
+        self.pad_token = d["pad_token"]
+        self.pad_token_id = self.vocab_size
+        self.vocab_size += 1
+        return 1
 
     def encode_ids(self, s, add_special_tokens=True):
         ids = [int(t) for t in s.split() if t.isdigit()]

@@ -345,6 +345,7 @@ class AdamW:
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.group, self.world, self.rank = group, world_size, rank
         self.step_no = 0
+        self.steps = [0] * len(self.params)   # torch.optim.AdamW keeps state['step'] PER PARAMETER: it only advances when the parameter has a gradient
         n = sum(p.numel() for p in self.params)
         gran = world_size * 64
         self.n, self.n_pad = n, (n + gran - 1) // gran * gran
@@ -363,10 +364,19 @@ class AdamW:
         self.gflat = torch.zeros(self.n_pad, device=dev, dtype=torch.float32)
 
     def step(self, grads):
-        """grads: {name: fp32 tensor} of THIS rank's micro-batch.  Returns the global gradient norm (before clipping)."""
+        """grads: {name: fp32 tensor} of THIS rank's micro-batch.  Returns the global gradient norm (before clipping).
+        A parameter without an entry (or None) had no gradient in this step — e.g. down_proj / up_proj on an image batch (T == 1
+        skips the pooling), mvm_decoder.* when no mask was drawn: like torch.optim.AdamW (`if p.grad is None: continue`) it is
+        left untouched (no decay, no moment update, its own step count does not advance) and does not enter the gradient norm."""
         import torch.distributed as dist
+        present = []
         for name, off, p in zip(self.names, self.offsets, self.params):
-            self.gflat[off: off + p.numel()] = grads[name].reshape(-1)
+            g = grads.get(name)
+            present.append(g is not None)
+            if g is None:
+                self.gflat[off: off + p.numel()].zero_()
+            else:
+                self.gflat[off: off + p.numel()] = g.reshape(-1)
         lo = self.rank * self.shard
         if self.world > 1:
             gshard = torch.empty(self.shard, device=self.gflat.device, dtype=torch.float32)
@@ -387,8 +397,28 @@ class AdamW:
             scale = min(1.0, self.max_norm / (norm + 1e-6))     # torch.nn.utils.clip_grad_norm_
         self.step_no += 1
         pshard = self.flat[lo: lo + self.shard]
-        hip.adamw(pshard, gshard, self.m, self.v, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
-                  weight_decay=self.wd, step=self.step_no, grad_scale=scale)
+        kw = dict(lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, grad_scale=scale)
+        if all(present) and len(set(self.steps)) == 1:
+            # the usual case: every parameter has a gradient and the same history -> ONE launch over the whole shard
+            self.steps = [self.steps[0] + 1] * len(self.steps)
+            hip.adamw(pshard, gshard, self.m, self.v, step=self.steps[0], **kw)
+        else:
+            # per-parameter step counts / skipped parameters: one launch per run of adjacent parameters that share a step count,
+            # restricted to this rank's slice of the flat buffer
+            runs = []   # [start, end, step]
+            for i, (off, p) in enumerate(zip(self.offsets, self.params)):
+                if not present[i]:
+                    continue
+                self.steps[i] += 1
+                a, b = off, off + p.numel()
+                if runs and runs[-1][1] == a and runs[-1][2] == self.steps[i]:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b, self.steps[i]])
+            for a, b, st in runs:
+                a, b = max(a, lo), min(b, lo + self.shard)
+                if a < b:
+                    hip.adamw(self.flat[a:b], gshard[a - lo: b - lo], self.m[a - lo: b - lo], self.v[a - lo: b - lo], step=st, **kw)
         if self.world > 1:
             dist.all_gather_into_tensor(self.flat, pshard.clone(), group=self.group)
         return norm
@@ -396,7 +426,7 @@ class AdamW:
     def state_dict(self):
         """this rank's optimizer state (HF Trainer / DeepSpeed write one optimizer shard per rank too): step count, hyper-parameters,
         the rank's slices of the moments; the masters live in the model's own state dict (trainable_state_dict)."""
-        return dict(step=self.step_no, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, world_size=self.world,
+        return dict(step=self.step_no, steps=list(self.steps), lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, world_size=self.world,
                     rank=self.rank, n=self.n, m=self.m.detach().cpu().clone(), v=self.v.detach().cpu().clone())
 
     def load_state_dict(self, sd):
@@ -404,6 +434,7 @@ class AdamW:
             raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world_size']} ({sd['n']} parameters) does not fit rank "
                              f"{self.rank}/{self.world} ({self.n})")
         self.step_no = int(sd["step"])
+        self.steps = [int(x) for x in sd["steps"]] if "steps" in sd else [self.step_no] * len(self.params)
         self.m.copy_(sd["m"].to(self.m.device))
         self.v.copy_(sd["v"].to(self.v.device))
 
@@ -429,6 +460,8 @@ def train_step(model, samples, optimizer, freeze_btadapter=False, drop_path=None
     loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter, drop_path)
     norm = optimizer.step(grads)
     invalidate_packed(model)
+    if loss.is_cuda:   # optimizer.step() read the gradient norm back: the stream is idle, check the split-K exchanges of this step
+        hip.gemm_workspace_check(loss.device, wait=True)
     return loss, loss_mvm, norm
 
 

@@ -13,6 +13,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     from stllm_amd import synth
     synth.enable_cache()  # the suites regenerate the same named full-width tensors many times
+    # the golden fixtures were generated through a fake LlamaTokenizer whose add_special_tokens is a no-op (tests/golden/ref_shim.py:
+    # 32000 words, pad id 0 in every mode); the product's stand-in defaults to HF's behaviour ('[PAD]' = id 32000, 32001 words,
+    # st_llm.py:306-310).  Replay the fixtures under the tokenizer they were made with; tests/test_checkpoint_cpu.py covers the HF mode.
+    from stllm_amd.tokenizer import IdTokenizer
+    IdTokenizer.hf_special_tokens = False
 
 
 def pytest_collection_modifyitems(config, items):

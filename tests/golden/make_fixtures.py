@@ -2,6 +2,7 @@
 
     python tests/golden/make_fixtures.py [name ...]      # default: all small fixtures
     python tests/golden/make_fixtures.py c1_full         # full-size config-1 summary (~15 min, 40 GB RAM)
+    python tests/golden/make_fixtures.py c2_full         # full-size config-2 (= bench.py's workload) summary
 
 Imports the reference's *own* model code (via ref_shim.py), fills its parameters with the
 deterministic generator ``stllm_amd.synth`` (so the weights never need to be stored: both the
@@ -472,10 +473,51 @@ def fx_c1_full():
          ref_forward_seconds=np.array([time.time() - t1]))
 
 
+def fx_pos_embed():
+    """the reference's interpolate_pos_embed (eva_vit.py:373-394) — a checkpoint whose position table was
+    trained at another resolution (here 26 x 26 = 364 px and 8 x 8 = 112 px) resampled to the model's 16 x 16 grid."""
+    ref = ref_shim.load_reference()
+    D = 24
+    import types
+    model = types.SimpleNamespace(patch_embed=types.SimpleNamespace(num_patches=256), pos_embed=torch.zeros(1, 257, D))
+    arrs = {}
+    for tag, n in (("up", 8), ("down", 26), ("same", 16)):
+        ck = {"pos_embed": T(f"pos_embed.{tag}", (1, 1 + n * n, D))}
+        arrs[f"{tag}.in"] = ck["pos_embed"].numpy().copy()
+        ref.eva.interpolate_pos_embed(model, ck)
+        arrs[f"{tag}.out"] = ck["pos_embed"].numpy()
+    save("pos_embed", **arrs)
+
+
+def fx_c2_full():
+    """Config 2 = the BENCHMARKED size: B1 T16, EVA-CLIP-g 39 blocks + 12-layer Q-Former + Vicuna-7B 32 layers, 'all' pooling,
+    S = 576 — exactly the samples bench.py times (bench.make_samples), through the reference's own forward on CPU (fp32).
+    Stores the same logits summary as c1_full."""
+    import bench   # repo root is on sys.path (see the top of this file)
+    t0 = time.time()
+    cfg = _Cfg(dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="",
+                    video_input="all", use_mask=False, mvm_decode=False,
+                    qformer_text_input=False, max_txt_len=32, end_sym=" 2", vit_precision="fp32"))
+    model = _build_ref_stllm(cfg, 39, 12, 32)
+    print("built", time.time() - t0, flush=True)
+    fill_stllm(model)
+    print("filled", time.time() - t0, flush=True)
+    samples = bench.make_samples(1, 16, "cpu")
+    t1 = time.time()
+    out = model(samples=samples)
+    print("forward", time.time() - t1, flush=True)
+    lg = out.logits[0]
+    top = lg.topk(5, dim=-1)
+    save("c2_full", logits_slice=lg[::3, ::499].numpy(), logits_stats=stats(lg), seq_len=np.array([lg.shape[0]]),
+         top_ids=top.indices.numpy(), top_vals=top.values.numpy(),
+         row_norms=lg.norm(dim=-1).numpy(), loss=np.array([out.loss.item()]),
+         ref_forward_seconds=np.array([time.time() - t1]))
+
+
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
            stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip,
-           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward)
-SLOW = dict(c1_full=fx_c1_full)
+           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward, pos_embed=fx_pos_embed)
+SLOW = dict(c1_full=fx_c1_full, c2_full=fx_c2_full)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

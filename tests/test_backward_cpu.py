@@ -230,3 +230,30 @@ def test_btadapter_branch_backward_with_stochastic_depth():
     for n in names:
         want = sd[n].grad
         assert (grads[n] - want).abs().max().item() <= 3e-4 * max(want.abs().max().item(), 1e-6), n
+
+
+def test_train_step_on_an_image_batch_skips_the_pooling_parameters():
+    """T == 1 (`use_image`, st_llm.py:324-326): the global-local module is bypassed, so down_proj / up_proj get no gradient —
+    loss_and_grads leaves them out and the optimizer (like torch.optim.AdamW with grad None) leaves them untouched."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build, make_inputs
+    from stllm_amd import runtime, training
+    cfg = CFGS["instructblip_residual_text"]
+    model = build(cfg, vit_depth=1, qf_layers=2, llm_layers=1)
+    samples, _ = make_inputs(2, 1, True)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        opt = training.AdamW(list(training.trainable_parameters(model)), lr=1e-3, max_grad_norm=1.0)
+        sm = model.model.stllm_model
+        pool = lambda n: n.startswith(("model.stllm_model.down_proj", "model.stllm_model.up_proj"))   # (not the LLM's mlp.down_proj / up_proj)
+        frozen_before = {n: p.detach().clone() for n, p in model.named_parameters() if pool(n)}
+        assert frozen_before
+        head_before = model.lm_head.weight.detach().clone()
+        loss, _, grads = training.loss_and_grads(model, samples)
+        assert not any(pool(n) for n in grads) and "lm_head.weight" in grads
+        l0, _, norm = training.train_step(model, samples, opt)
+        assert norm > 0 and not torch.equal(head_before, model.lm_head.weight)
+        for n, p in model.named_parameters():
+            if n in frozen_before:
+                assert torch.equal(p, frozen_before[n]), n
+        i_skip = [i for i, n in enumerate(opt.names) if pool(n)]
+        assert i_skip and all(opt.steps[i] == 0 for i in i_skip) and max(opt.steps) == 1

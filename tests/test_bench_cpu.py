@@ -1,0 +1,40 @@
+"""CPU (gloo, world_size 2): bench.py's own multi-rank code path — self-spawned ranks, frame-parallel encode, the all-gather,
+clip-parallel prefill, max-over-ranks timing, the JSON contract — at reduced depth on the contract backend (`--dry-cpu`).
+A plumbing check: the numbers mean nothing, the structure of the line and the absence of a launcher requirement do."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--dry-cpu", "--steps", "1", "--warmup", "1", "--vit-depth", "1", "--qformer-layers", "2", "--llm-layers", "1", "--frames", "2"]
+
+
+def _run(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("config,scaling,batch", [("c3", "strong", 4), ("c2", "weak", 2)])
+def test_bench_self_spawns_two_ranks(config, scaling, batch):
+    res = _run(["--gpus", "2", "--config", config])
+    assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["config"]["name"] == config
+    assert res["config"]["global_batch"] == batch and res["steps"] == 1 and res["higher_is_better"] is True
+    assert res["value"] > 0 and res["ms_per_step"] > 0 and res["allgather_us"] > 0
+    assert res["allgather_bytes_per_rank"] == (batch * 2 // 2) * 32 * 4096 * 4
+    assert "frame-parallel x2" in res["config"]["parallelism"] and "DRY RUN" in res["data"]
+    assert res["loss"] == res["loss"], "rank 0 owns clip 0: its loss must be a number"
+    if config == "c3":
+        assert res["config"]["video_tokens_per_clip"] == 2 * 32 and "residual" in res["config"]["workload"]   # R clamped to the 2 frames of the dry run
+
+
+def test_bench_single_rank_dry():
+    res = _run(["--gpus", "1", "--config", "c2"])
+    assert res["n_gpus"] == 1 and res["scaling"] == "weak" and "allgather_us" not in res
+    assert res["config"]["video_tokens_per_clip"] == 2 * 32 and "REDUCED" in res["config"]["workload"]

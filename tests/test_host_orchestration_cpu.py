@@ -154,10 +154,11 @@ def _fp_worker(rank, world, port, cfg_name, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg_name", ["instructblip_residual_text", "minigpt4_mask_mvm"])
+@pytest.mark.parametrize("cfg_name", ["instructblip_residual_text", "btadapter", "minigpt4_mask_mvm"])
 def test_frame_parallel_model_matches_single_process(cfg_name):
     """N=2 ranks: frames sharded, ONE all-gather, each rank prefills the clips it owns — logits bit-identical to the
-    unsharded run for those clips (the all-gather moves bits; every kernel sees the same rows in the same order)."""
+    unsharded run for those clips (the all-gather moves bits; every kernel sees the same rows in the same order).
+    BT-Adapter backbone: whole clips per rank (its temporal attention couples the frames of a clip), no collective."""
     if cfg_name == "minigpt4_mask_mvm":
         pytest.skip("masking draws from the numpy RNG per rank; the injected-mask variant is covered on the GPU")
     world = 2
@@ -180,7 +181,8 @@ def test_frame_parallel_model_matches_single_process(cfg_name):
         for j, c in enumerate(own):
             a, b = logits[j], single[c, :S] if single.shape[1] >= S else single[c]
             n = min(a.shape[0], b.shape[0])
-            assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 1e-5, f"rank {rank} clip {c}"
+            # (the contract backend's CPU BLAS blocks a 1-clip and a 3-clip GEMM differently: a few fp32 ulps, not bits)
+            assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 5e-5, f"rank {rank} clip {c}"
     assert sorted(seen) == [0, 1, 2]
 
 
@@ -219,7 +221,7 @@ def test_chat_answer_beam_search_on_host_graph():
         chat.upload_video(frames.view(6, 224, 224), None, img_list)
         text, ids = chat.answer(img_list, [21, 22, 23], max_new_tokens=4, num_beams=3, do_sample=False)
         embs, _ = chat.get_context_emb_ids(img_list, [21, 22, 23])
-        direct = model.generate(inputs_embeds=embs, max_new_tokens=4, num_beams=3, min_length=1)
+        direct = model.generate(inputs_embeds=embs, max_new_tokens=4, num_beams=3, min_length=1, repetition_penalty=1.5)   # the sim path's override (conversation.py:219-220)
     d = direct[0]
     while d.numel() and int(d[0]) in (0, 1) and d.numel() > ids.size:
         d = d[1:]
@@ -248,3 +250,25 @@ def test_generate_matches_reference_fixture():
                               temperature=1.0), **kw)
                 ids = model.generate(inputs_embeds=emb, **k)[0].tolist()
                 assert ids == g[f"s{scale:g}_p{seed}_m{mi}"].tolist(), (scale, seed, kw, ids)
+
+
+def test_packed_weight_caches_follow_in_place_edits_of_the_masters():
+    """LlamaModel / ViT / Q-Former cache their packed compute-dtype weights; an in-place edit of a master parameter
+    (p.data.copy_, an external optimizer, synth fill after a forward) must not keep running on the stale packed copy."""
+    from stllm_amd import runtime
+    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=1)
+    samples, _ = make_inputs(1, 2, False)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        a = model(samples=samples).logits.clone()
+        assert torch.equal(model(samples=samples).logits, a)
+        with torch.no_grad():
+            model.model.layers[0].mlp.down_proj.weight.mul_(0.5)                     # LLM cache
+        b = model(samples=samples).logits.clone()
+        assert not torch.equal(a, b)
+        with torch.no_grad():
+            model.model.stllm_model.visual_encoder.blocks[0].mlp.fc1.weight.mul_(0.5)   # ViT cache
+        c = model(samples=samples).logits.clone()
+        assert not torch.equal(b, c)
+        with torch.no_grad():
+            model.model.stllm_model.Qformer.bert.encoder.layer[1].attention.self.query.weight.mul_(0.5)   # Q-Former cache
+        assert not torch.equal(c, model(samples=samples).logits)

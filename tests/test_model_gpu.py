@@ -295,7 +295,45 @@ def test_c1_full_size_vs_reference():
             assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
             assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
             assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
-    assert res["fp16"][0] <= 0.2 and res["bf16"][0] <= 1.5
+    # fast modes: measured 2.5e-2 / 0.993 (fp16) and 1.7e-1 / 0.926 (bf16) in round 1 — bounded with ~1.5x margin, not the vacuous 0.2 / 1.5
+    assert res["fp16"][0] <= 0.04 and res["fp16"][1] >= 0.985, res["fp16"]
+    assert res["bf16"][0] <= 0.25 and res["bf16"][1] >= 0.90, res["bf16"]
+
+
+def test_c2_full_size_vs_reference():
+    """BASELINE config 2 — the BENCHMARKED workload (bench.make_samples(1, 16): B1 T16, 39 + 12 + 32 layers, S = 576, the phased
+    GEMM dispatch with q = 2 rounds + K-split remainder at M = 4112) against the summary of the logits the REFERENCE's own
+    forward produced on CPU in fp32 on the same inputs and synthetic weights (tests/golden/make_fixtures.py c2_full)."""
+    import bench
+    from stllm_amd import runtime
+    g = golden("c2_full")
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False,
+               mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=39, qf_layers=12, llm_layers=32)
+    samples = bench.make_samples(1, 16, "cuda")
+    res = {}
+    for mode in ("fp32", "fp16", "bf16"):
+        with runtime.use_dtype(mode):
+            for m in (model.model.stllm_model.visual_encoder, model.model.stllm_model.Qformer.bert, model.model):
+                m.repack()
+            model._lm_packed = {}
+            out = model(samples=samples)
+        assert out.logits.shape[1] == int(g["seq_len"][0]) == 576
+        lg = out.logits[0].float().cpu()
+        err = float(np.abs(lg[::3, ::499].numpy() - g["logits_slice"]).max())
+        agree = float((lg.argmax(-1).numpy() == g["top_ids"][:, 0]).mean())
+        res[mode] = (err, agree, float(out.loss.item()))
+        print(f"\n[c2_full {mode}] logits max-abs err {err:.3e} (abs-max {g['logits_stats'][1]:.2f}), top-1 agreement "
+              f"{agree:.3f}, loss {out.loss.item():.5f} vs {g['loss'][0]:.5f}")
+        if mode == "fp32":
+            top = lg.topk(5, dim=-1)
+            assert err <= 1e-2 and agree >= 0.99
+            assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
+            assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
+            assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
+    assert res["fp16"][0] <= 0.05 and res["fp16"][1] >= 0.98, res["fp16"]
+    assert res["bf16"][0] <= 0.3 and res["bf16"][1] >= 0.88, res["bf16"]
+    assert abs(res["bf16"][2] - g["loss"][0]) <= 0.05 and abs(res["fp16"][2] - g["loss"][0]) <= 0.01
 
 
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 5e-2)])

@@ -43,6 +43,34 @@ def test_adamw_matches_torch(wd, clip):
                 assert torch.allclose(p, rp, rtol=2e-6, atol=2e-7), (n, step, (p - rp).abs().max())
 
 
+def test_adamw_skips_parameters_without_a_gradient_like_torch():
+    """Image batches (T == 1: no pooling -> no down_proj / up_proj gradient) and un-masked batches (no mvm_decoder gradient) give
+    loss_and_grads dictionaries WITHOUT those names: torch.optim.AdamW skips a parameter whose .grad is None (no decay, no moment
+    update, its per-parameter step count stays), clip_grad_norm_ ignores it."""
+    from stllm_amd import training
+    named = _params()
+    ref_p = [torch.nn.Parameter(p.detach().clone()) for _, p in named]
+    ref = torch.optim.AdamW(ref_p, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    missing_at = {0: ("p1",), 1: (), 2: ("p1", "p2"), 3: ("p0",), 4: ()}
+    with _cpu_backend.installed():
+        opt = training.AdamW(named, lr=3e-3, weight_decay=0.02, max_grad_norm=0.7)
+        for step in range(5):
+            grads = {n: g for n, g in _grads(named, step).items() if n not in missing_at[step]}
+            for rp, (n, _) in zip(ref_p, named):
+                rp.grad = grads[n].clone() if n in grads else None
+            want_norm = torch.nn.utils.clip_grad_norm_(ref_p, 0.7).item()
+            ref.step()
+            got_norm = opt.step(grads)
+            assert abs(got_norm - want_norm) <= 1e-5 * want_norm
+            for rp, (n, p) in zip(ref_p, named):
+                assert torch.allclose(p, rp, rtol=2e-6, atol=2e-7), (n, step, (p - rp).abs().max())
+        assert opt.steps == [4, 3, 4, 5]
+        sd = opt.state_dict()
+        opt2 = training.AdamW(_params(), lr=3e-3, weight_decay=0.02, max_grad_norm=0.7)
+        opt2.load_state_dict(sd)
+        assert opt2.steps == opt.steps
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
