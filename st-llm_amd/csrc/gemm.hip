@@ -905,11 +905,12 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
-    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): 0 = keep M <= 4 on the tile kernels, 2 = GEMV up to M = 8
+    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): -1 / 2 = GEMV up to M = 8 (the 5 beams of demo.py), 1 = up to M = 4, 0 = off
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
     const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
-    if (p.M <= (gemv_mode == 2 ? 8 : 4) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
+    // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench_before.log)
+    if (p.M <= (gemv_mode == 1 ? 4 : 8) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
     }

@@ -1,10 +1,8 @@
 """GPU (-m gpu): the training entry points on the device.
 
-These kernels were written after round 1's GPU minutes were spent: their logic is covered on the CPU by the emulated build
-(tests/test_kernels_emulated_cpu.py) and the host graph by tests/test_backward_cpu.py, but THIS file had not run on
-hardware when it was committed.  Hence (a) every check runs in a child process with a timeout, so that a device fault cannot
-take the rest of the GPU suite down, and (b) the tests are xfail(strict=False): XPASS = parity on the device, XFAIL = work
-for the next round.  Remove the marker once they have passed on an MI355X.
+First run on hardware: the round-1 driver run (GPUTEST_r01.json: all three XPASS on an MI355X) — the staging xfail marker is
+gone, a failure here is a regression.  Every check still runs in a child process with a timeout, so that a device fault cannot
+take the rest of the GPU suite down.
 
 1. every kernel case of test_kernels_emulated_cpu.py, through the real C ABI on cuda:0 (same tolerances);
 2. loss_and_grads on the device against the reference's gradient fixture — MVM/mask, residual pooling + text, and the BT-Adapter
@@ -18,7 +16,6 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIRST_RUN = pytest.mark.xfail(strict=False, reason="not yet run on hardware: round-1 GPU budget was spent before these kernels existed")
 
 
 def _child(args, timeout, env_extra=None):
@@ -30,7 +27,6 @@ def _child(args, timeout, env_extra=None):
 
 
 @pytest.mark.gpu
-@FIRST_RUN
 def test_training_kernels_on_device():
     out = _child(["-m", "pytest", "tests/test_kernels_emulated_cpu.py", "-q", "-x", "-k", "not entirely_on_emulated_kernels", "-p", "no:cacheprovider"],
                  timeout=900, env_extra={"STLLM_TRAIN_KERNELS_ON_DEVICE": "1"})
@@ -81,7 +77,6 @@ for tag in sys.argv[2].split(","):
 
 
 @pytest.mark.gpu
-@FIRST_RUN
 @pytest.mark.parametrize("mode,tags", [("fp32", "mvm,residual,btadapter"), ("bf16", "mvm")])
 def test_training_step_on_device_matches_reference_gradients(mode, tags):
     out = _child(["-c", _STEP, mode, tags], timeout=900)
