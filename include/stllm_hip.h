@@ -115,7 +115,8 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_w4"    = -1 auto (cost model vs the phased kernel) | 0 off | 1 always | 34 / 44 always, 192 x 256 / 256 x 256 tile:
+ *   "gemm_w4"    = -1 auto (currently: never) | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
+ *                  other kernels' estimates | 32 / 34 / 44 always, 192 x 128 / 192 x 256 / 256 x 256 tile:
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 8) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernel of the decode regime (st-llm_amd/csrc/gemv.hip);
  *                  M <= 8 covers the 5 beams of demo.py's beam search (6.99 -> 6.02 ms per 5-row step on MI355X)

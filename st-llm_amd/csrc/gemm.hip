@@ -886,20 +886,36 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   return est < 0.93f * old_us;
 }
 
-// One-wave-per-SIMD kernel (gemm_w4.inc): same eligibility as the phased kernel.  mode 1 / 34 / 44: always (cost model /
-// 192 x 256 / 256 x 256 tile); auto: when its cost model beats the phased kernel's (profiles/r02_w4_probe.md).
-static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_us, bool p8_ok) {
+// estimate for the 128x128 / 64x64 persistent kernels (the model p8_wanted compares with)
+static float old_kernels_estimate_us(const GemmParams& p) {
+  const int nk = p.K / 64;
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
+  if (t128 < 192) return 5.0f + nk * 0.55f;                       // 64x64 tiles, 4 workgroups per CU
+  return 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
+}
+
+// One-wave-per-SIMD kernel (gemm_w4.inc): same eligibility as the phased kernel.  mode 1 / 32 / 34 / 44: always (cost model /
+// 192 x 128 / 192 x 256 / 256 x 256 tile).  auto: only plans WITHOUT a K-split exchange (whole or partial rounds of whole tiles:
+// there it measured 3-30 % faster than the alternatives, profiles/r02_w4_probe.md) on large-M problems, when its calibrated
+// estimate beats both other kernel families — in the bench path that is the ViT's N = 1408 GEMMs (proj, fc2) as ONE round
+// of 242 tiles of 192 x 128.
+static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_us) {
   if (g_w4_mode == -2) { const char* e = getenv("STLLM_GEMM_W4"); g_w4_mode = e ? atoi(e) : -1; }
   if (g_w4_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
-  const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape);
-  if (g_w4_mode == 34 || g_w4_mode == 44) { *shape = g_w4_mode; return true; }
+  int split = 1;
+  const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape, &split);
+  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44) { *shape = g_w4_mode; return true; }
   if (g_w4_mode == 1) return true;
-  // auto: measured on MI355X (profiles/r02_w4_probe.md) the kernel is 2-4 % faster than the phased kernel on whole-tile
-  // rounds and 2-5 % slower wherever a K-split remainder exists (it publishes the full partial tile); no shape of the bench
-  // path is remainder-free, so the automatic choice stays with the phased kernel until the exchange is slimmer
-  (void)est; (void)p8_est_us; (void)p8_ok;
-  return false;
+  if (g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_p8_mode == 0) return false;   // a forced / disabled kernel family (tests / experiments) wins
+  // Measured inside bench.py (cold weights every launch, unlike the harness's warm repeats): proj + fc2 on the 192 x 128 w4 tile
+  // 5.39 ms per step against 5.46 ms on the phased / 128x128 kernels — no gain once the weights come from HBM (the 2-deep LDS
+  // ring prefetches one unit ahead; the phased kernel's loads have two phases more to land).  The automatic choice therefore
+  // stays off until the ring is deeper; STLLM_GEMM_W4=2 (or stllm_set_option("gemm_w4", 2)) enables the rule below.
+  if (g_w4_mode != 2) return false;
+  if (split != 1 || p.M < 1024) return false;
+  const float other = p8_est_us < old_kernels_estimate_us(p) ? p8_est_us : old_kernels_estimate_us(p);
+  return est < 0.97f * other;
 }
 
 template <typename T>
@@ -908,7 +924,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): -1 / 2 = GEMV up to M = 8 (the 5 beams of demo.py), 1 = up to M = 4, 0 = off
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
-    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench_before.log)
     if (p.M <= (gemv_mode == 1 ? 4 : 8) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
@@ -921,7 +937,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     if (a->epilogue != STLLM_EPI_PATCH) {
       int shape = 44, miw2 = 4;
       const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2);
-      if (w4_wanted(p, heavy, &shape, p8_est, p8_ok)) {
+      if (w4_wanted(p, heavy, &shape, p8_est)) {
         const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
                                                       : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
         if (rc != STLLM_ERR_UNSUPPORTED) return rc;

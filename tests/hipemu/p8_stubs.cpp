@@ -8,4 +8,4 @@ float stllm_gemm_p8_estimate_us(int, int, int, int, int* miw) { if (miw) *miw = 
 extern "C" int stllm_gemm_plan(int, int, int, int, int, int*) { return STLLM_ERR_UNSUPPORTED; }
 int stllm_gemm_w4_launch_bf16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
 int stllm_gemm_w4_launch_f16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
-float stllm_gemm_w4_estimate_us(int, int, int, int, int* shape) { if (shape) *shape = 44; return 1.0e30f; }
+float stllm_gemm_w4_estimate_us(int, int, int, int, int* shape, int* split) { if (shape) *shape = 44; if (split) *split = 1; return 1.0e30f; }

@@ -67,11 +67,11 @@ def test_w4_gemm_schedule_invariants():
     from stllm_amd import hip
     shapes_ = [(4112, 4224, 1408), (4112, 6144, 1408), (4112, 1408, 6144), (576, 12288, 4096), (576, 22016, 4096), (576, 4096, 11008),
                (4096, 4096, 4096), (1, 128, 64), (300, 384, 192), (100000, 256, 64), (3072, 8192, 1408)]
-    for shape, rows in ((34, 192), (44, 256)):
+    for shape, rows, cols in ((34, 192, 256), (44, 256, 256), (32, 192, 128)):
         for M, N, K in shapes_:
             for heavy in (0, 1, 2):
                 q, r, s, cap, est = hip.gemm_w4_plan(M, N, K, heavy, shape)
-                tiles = -(-M // rows) * -(-N // 256)
+                tiles = -(-M // rows) * -(-N // cols)
                 assert q * 256 + r == tiles and 0 <= r < 256, (M, N, K, rows, q, r)
                 assert 1 <= s <= 32 and cap == 32 // s and est > 0
                 if r:
@@ -80,6 +80,7 @@ def test_w4_gemm_schedule_invariants():
                     assert s == 1
     assert hip.gemm_w4_plan(3072, 8192, 1408, 0, 34)[:3] == (2, 0, 1)          # 512 tiles of 192 x 256: two whole rounds
     assert hip.gemm_w4_plan(4096, 4096, 4096, 0, 44)[:3] == (1, 0, 1)
+    assert hip.gemm_w4_plan(4112, 1408, 6144, 1, 32)[:3] == (0, 242, 1)        # ViT fc2 / proj: 242 tiles of 192 x 128 = one partial round, no K split
     with pytest.raises(RuntimeError):
         hip.gemm_w4_plan(576, 4096, 4096, 0, 33)
 

@@ -369,7 +369,7 @@ def test_gemm_bench_shapes_auto_dispatch(hip, M, N, K, kind):
 W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7), (2100, 2944, 256), (3072, 2048, 704)]
 
 
-@pytest.mark.parametrize("shape", [34, 44])
+@pytest.mark.parametrize("shape", [32, 34, 44])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 def test_gemm_w4(hip, dtype, shape, M, N, K):
@@ -402,7 +402,7 @@ def test_gemm_w4(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
-@pytest.mark.parametrize("shape", [34, 44])
+@pytest.mark.parametrize("shape", [32, 34, 44])
 def test_gemm_w4_swiglu_rope_rows(hip, shape):
     from stllm_amd import pack
     dtype = "bf16"
