@@ -285,19 +285,21 @@ def _run(args, world, rank, device, dry):
     if world > 1:
         from stllm_amd import parallel
         n_frames = B * T
-        s0, e0 = parallel.frame_range(n_frames, rank, world)
+        load = sm._prefill_load(B, T, world)
+        s0, e0 = parallel.frame_range(n_frames, rank, world, load)
         local = torch.zeros((e0 - s0, 32, 4096), dtype=torch.float32, device=device)
         for _ in range(3):
-            parallel.all_gather_frames(local, n_frames, rank, world)
+            parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
         sync()
         t1 = time.perf_counter()
         reps = 2 if dry else 20
         for _ in range(reps):
-            parallel.all_gather_frames(local, n_frames, rank, world)
+            parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
         sync()
         ag_us = (time.perf_counter() - t1) / reps * 1e6
 
     if rank == 0:
+        from stllm_amd import parallel
         Lt = 24 if text else 0
         flop_clip = algorithmic_flops(T, S, Lt)
         step_s = dt_s / args.steps
@@ -317,7 +319,9 @@ def _run(args, world, rank, device, dry):
                "end_to_end_tflops_per_gpu": round(B * flop_clip / step_s / 1e12 / world, 1)}
         if world > 1:
             res["allgather_us"] = round(ag_us, 1)
-            res["allgather_bytes_per_rank"] = (B * T // world) * 32 * 4096 * 4
+            counts = parallel.frame_counts(B * T, world, sm._prefill_load(B, T, world))
+            res["frames_per_rank"] = counts     # levelled against the prefill load of each rank (stllm_amd.parallel.frame_counts)
+            res["allgather_bytes_per_rank"] = max(counts) * 32 * 4096 * 4
             if conf["scaling"] == "weak":
                 res["scaling_note"] = ("c2 at N > 1 is weak scaling (one clip per GPU; each rank's frame range is its own clip, so the all-gather "
                                        "carries no remote token the prefill needs); the frame-parallel experiment is --config c3 (strong scaling)")

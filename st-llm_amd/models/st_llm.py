@@ -108,6 +108,23 @@ class STLLMModel(Blip2Base):
         clip — rank r encodes AND prefills the clips c with c % world == r, no collective (SURVEY.md §8e "shard by clip")."""
         self.frame_parallel = (rank, world, group) if world > 1 else None
 
+    # encode time of one frame = 1; one prefilled clip of ~576 positions costs about this many frames (algorithmic FLOPs 7.7 T vs
+    # 0.534 T per frame = 14.4, times the measured efficiency ratio of the ViT and Llama GEMM shapes on one MI355X: c2 spends
+    # 11.8 ms in the LLM and 0.96 ms per frame); used to level the frame ranges when a batch has fewer clips than ranks
+    prefill_cost_frames = 12.0
+
+    def _prefill_load(self, n_clips, T, world):
+        """frames-equivalent of the prefill work of every rank (clip c -> rank c % world), scaled with the visual tokens per clip"""
+        from .. import parallel
+        if self.video_input == "residual":
+            lvis = self.residual_size * 32
+        elif self.video_input == "mean":
+            lvis = 32
+        else:
+            lvis = T * 32
+        per_clip = self.prefill_cost_frames * (lvis + 64) / 576.0
+        return [len(parallel.clips_of_rank(n_clips, r, world)) * per_clip for r in range(world)]
+
     # ------------------------------------------------------------------------------------------
     def _qformer_ids(self, text, n_frames, T):
         """st_llm.py:337-350: BERT-tokenise the instruction, one copy per frame."""
@@ -130,15 +147,16 @@ class STLLMModel(Blip2Base):
             rank, world, group = self.frame_parallel
             frames = image.reshape((-1,) + tuple(image.shape[2:]))
             qtext = text
+            load = self._prefill_load(image.shape[0], T, world)
 
             def enc_local(fr, _s=[0]):
-                s0, _ = parallel.frame_range(frames.shape[0], rank, world)
+                s0, _ = parallel.frame_range(frames.shape[0], rank, world, load)
                 t_local = None
                 if self.qformer_text_input:  # each rank needs the text of the clips its frames belong to
                     all_t = [qtext] * frames.shape[0] if isinstance(qtext, str) else [t for t in qtext for _ in range(T)]
                     t_local = all_t[s0: s0 + fr.shape[0]]
                 return self._encode_frames(fr, t_local, T, dt)
-            tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group)
+            tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load)
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
             atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
             return inputs_llama, atts_llama, use_image

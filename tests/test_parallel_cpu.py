@@ -23,25 +23,26 @@ def _encode(frames):
     return torch.tanh(x * 1.7) + x.flip(-1) * 0.25
 
 
-def _worker(rank, world, port, n_frames, q):
+def _worker(rank, world, port, n_frames, q, extra=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from stllm_amd import parallel
     torch.manual_seed(0)
     frames = torch.randn(n_frames, 3, 16, 16)
-    tokens = parallel.encode_frames_parallel(_encode, frames, rank, world, token_shape=(32, 8))
-    q.put((rank, tokens.clone(), parallel.frame_range(n_frames, rank, world), parallel.clips_of_rank(5, rank, world)))
+    tokens = parallel.encode_frames_parallel(_encode, frames, rank, world, token_shape=(32, 8), extra=extra)
+    q.put((rank, tokens.clone(), parallel.frame_range(n_frames, rank, world, extra), parallel.clips_of_rank(5, rank, world)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [32, 7, 1])
-def test_frame_parallel_allgather_matches_single_process(n_frames):
+@pytest.mark.parametrize("n_frames,extra", [(32, None), (7, None), (1, None), (32, [12.0, 0.0]), (9, [0.0, 30.0])])
+def test_frame_parallel_allgather_matches_single_process(n_frames, extra):
+    """extra = the prefill load of every rank in frame units: uneven (even empty) frame ranges, same gathered block"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q, extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
@@ -56,6 +57,10 @@ def test_frame_parallel_allgather_matches_single_process(n_frames):
         ranges[rank] = fr
         assert clips == [c for c in range(5) if c % world == rank]
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_frames
+    if extra == [12.0, 0.0]:
+        assert ranges[0] == (0, 10) and ranges[1] == (10, 32)        # 10 + 12 == 22 + 0: both ranks finish together
+    if extra == [0.0, 30.0]:
+        assert ranges[0] == (0, 9) and ranges[1] == (9, 9)           # the loaded rank only takes part in the collective
 
 
 def test_frame_range_and_clip_ownership():
@@ -67,3 +72,13 @@ def test_frame_range_and_clip_ownership():
             assert max(e - s for s, e in r) - min(e - s for s, e in r) <= 1
     owned = sorted(c for k in range(8) for c in parallel.clips_of_rank(4, k, 8))
     assert owned == [0, 1, 2, 3]
+    # config 3 on 8 GPUs: 4 clips x 64 frames, ranks 0-3 also prefill one clip (~12 frames of work each)
+    assert parallel.frame_counts(256, 8, [12.0] * 4 + [0.0] * 4) == [26, 26, 26, 26, 38, 38, 38, 38]
+    assert parallel.frame_counts(256, 8, [12.0] * 8) == [32] * 8 == parallel.frame_counts(256, 8)
+    for n in (1, 7, 16, 64, 256):
+        for w in (2, 4, 8):
+            for ex in ([5.0 * (k % 2) for k in range(w)], [100.0] + [0.0] * (w - 1), [float(k) for k in range(w)]):
+                c = parallel.frame_counts(n, w, ex)
+                assert sum(c) == n and min(c) >= 0
+                lv = [c[k] + ex[k] for k in range(w) if c[k] > 0]
+                assert max(lv) - min(lv) <= 1.0 + 1e-9, (n, w, ex, c)    # levelled to within one frame among the ranks that got frames
