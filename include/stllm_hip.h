@@ -99,6 +99,12 @@ typedef struct {
    * memory, 16-byte aligned, private to the launch stream (launches on one stream may share it).  NULL => the
    * small-tile kernel is used for every shape.  Contents need no initialisation beyond one memset at allocation. */
   void* workspace; int64_t workspace_bytes;
+  /* optional, ABI version >= 2 (decode regime: M <= 8, 16-bit dtypes, every epilogue but PATCH): the A operand is not read
+   * from memory but computed on the fly as  RMSNorm(x) * gamma  cast to `dtype` — Llama's input_layernorm /
+   * post_attention_layernorm (modeling_llama_mem.py:61-78) fused into the projection that follows it in the one-token step.
+   * a_norm_x: fp32 rows [M, K], row stride a_norm_ldx elements; a_norm_gamma: fp32 [K].  A / lda are ignored (may be NULL / 0).
+   * Outside the decode regime the call is rejected (STLLM_ERR_UNSUPPORTED): run stllm_rmsnorm first. */
+  const float* a_norm_x; int64_t a_norm_ldx; const float* a_norm_gamma; float a_norm_eps;
 } stllm_gemm_args;
 int64_t stllm_gemm_workspace_bytes(void);
 /* Synchronises `stream` and returns 0 when no GEMM launch that used `workspace` ever gave up waiting for a peer workgroup
@@ -120,6 +126,7 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 8) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernel of the decode regime (st-llm_amd/csrc/gemv.hip);
  *                  M <= 8 covers the 5 beams of demo.py's beam search (6.99 -> 6.02 ms per 5-row step on MI355X)
+ *   "attn_decode_single" = 1 (default) one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
 int stllm_set_option(const char* key, int value);

@@ -571,6 +571,102 @@ __global__ __launch_bounds__(64) void attn_decode_merge_kernel(const AttnParams 
   *op = Elem<T>::pack2(a0 * inv, a1 * inv);
 }
 
+// ---- single-pass decode attention (round 2): ONE workgroup of 16 waves per (batch, head) ---------------------------------------
+// The split-KV pair above costs two launches (10.5 + 7.7 us per layer at Skv = 580) for 0.3 MB of K/V per head.  Here a wave works on
+// FOUR keys at a time: 16 lanes per key, 8 dims = one 16-byte load per lane for K and for V (4x wider than the 4-byte loads above),
+// a 4-step butterfly inside the 16-lane group, an online-softmax state per lane group; the next step's K/V are requested before the
+// current step is consumed.  The 4 x 16 partial states of the workgroup are merged through LDS (8.3 KB).  Used when the cache is
+// short enough that 16 waves per head cover it in a few steps (Skv <= kDecSingleMax) or when B * H alone fills the chip.
+constexpr int kDecSingleMax = 1536;
+constexpr int kDecWaves = 16;
+
+template <typename T> __device__ __forceinline__ void widen8v(i32x4 v, float* f);
+template <> __device__ __forceinline__ void widen8v<bf16_t>(i32x4 v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __builtin_bit_cast(float, (uint32_t)v[e] << 16);
+    f[2 * e + 1] = __builtin_bit_cast(float, (uint32_t)v[e] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void widen8v<f16_t>(i32x4 v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t u = (uint32_t)v[e];
+    f[2 * e] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu));
+    f[2 * e + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * kDecWaves) void attn_decode_single_kernel(const AttnParams p) {
+  __shared__ float part[kDecWaves * 4][kDecRec];   // one (m, l, O[128]) record per 16-lane group
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, l16 = lane & 15;     // key within the wave's quad, dims 8 * l16 .. + 7
+  const int h = blockIdx.x, b = blockIdx.y;
+  float q[8];
+  widen8v<T>(*reinterpret_cast<const i32x4*>(p.q + ((int64_t)b * p.q_bs + (int64_t)h * kDecD + 8 * l16) * 2), q);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] *= p.scale_log2;
+  const char* kb = p.k + ((int64_t)b * p.k_bs + (int64_t)h * kDecD + 8 * l16) * 2;
+  const char* vb = p.v + ((int64_t)b * p.v_bs + (int64_t)h * kDecD + 8 * l16) * 2;
+  float m = kNeg, l = 0.0f, o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.0f;
+  const int step = kDecWaves * 4;
+  int kbase = wave * 4;                              // wave-uniform: all four lane groups run the same number of steps
+  i32x4 kn = {0, 0, 0, 0}, vn = {0, 0, 0, 0};
+  if (kbase + grp < p.Skv) {
+    kn = *reinterpret_cast<const i32x4*>(kb + (int64_t)(kbase + grp) * p.k_rs * 2);
+    vn = *reinterpret_cast<const i32x4*>(vb + (int64_t)(kbase + grp) * p.v_rs * 2);
+  }
+  for (; kbase < p.Skv; kbase += step) {
+    const int key = kbase + grp;
+    const bool live = key < p.Skv;
+    const i32x4 kc = kn, vc = vn;
+    const int nk = key + step;
+    if (nk < p.Skv) {   // request the next quad of this wave before this one is consumed
+      kn = *reinterpret_cast<const i32x4*>(kb + (int64_t)nk * p.k_rs * 2);
+      vn = *reinterpret_cast<const i32x4*>(vb + (int64_t)nk * p.v_rs * 2);
+    }
+    float kf[8], vf[8];
+    widen8v<T>(kc, kf);
+    widen8v<T>(vc, vf);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(q[e], kf[e], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);                       // log2-domain score of this group's key, identical in its 16 lanes
+    if (live) {
+      const float mn = fmaxf(m, s);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn), pr = __builtin_amdgcn_exp2f(s - mn);
+      l = fmaf(l, alpha, pr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = fmaf(o[e], alpha, pr * vf[e]);
+      m = mn;
+    }
+  }
+  float* rec = part[wave * 4 + grp];
+  if (l16 == 0) { rec[0] = m; rec[1] = l; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rec[2 + 8 * l16 + e] = o[e];
+  __syncthreads();
+  if (threadIdx.x < kDecD) {
+    const int d = threadIdx.x;
+    float mm = kNeg;
+    for (int r = 0; r < kDecWaves * 4; ++r) mm = fmaxf(mm, part[r][0]);
+    float ll = 0.0f, acc = 0.0f;
+    for (int r = 0; r < kDecWaves * 4; ++r) {
+      const float f = __builtin_amdgcn_exp2f(part[r][0] - mm);
+      ll = fmaf(part[r][1], f, ll);
+      acc = fmaf(part[r][2 + d], f, acc);
+    }
+    store_elem<T>(p.o, (int64_t)b * p.o_bs + (int64_t)h * kDecD + d, acc / ll);
+  }
+}
+
+static int g_decode_single = 1;   // stllm_set_option("attn_decode_single", 0): always the split-KV pair (tests compare both)
 static int decode_splits(int Skv) {
   int n = (Skv + 47) / 48;   // ~48 keys (12 per wave) per workgroup
   return n < 1 ? 1 : (n > 64 ? 64 : n);
@@ -611,6 +707,8 @@ extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q
   return STLLM_ERR_BAD_DTYPE;
 }
 
+void stllm_attention_set_decode_single(int on) { g_decode_single = on; }
+
 extern "C" int64_t stllm_attention_decode_workspace_bytes(int B, int H, int Skv) {
   if (B <= 0 || H <= 0 || Skv <= 0) return -1;
   return (int64_t)B * H * decode_splits(Skv) * kDecRec * 4;
@@ -637,6 +735,13 @@ extern "C" int stllm_attention_decode(int dtype, const void* q, int64_t q_bs, co
   p.o = (char*)out; p.o_bs = o_bs;
   p.B = B; p.H = H; p.Sq = 1; p.Skv = Skv; p.D = D;
   p.scale = scale; p.scale_log2 = scale * 1.44269504088896340736f;
+  if ((Skv <= kDecSingleMax || B * H >= 256) && aligned16(q) && aligned16(k) && aligned16(v) && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+      k_rs % 8 == 0 && v_bs % 8 == 0 && v_rs % 8 == 0 && g_decode_single) {
+    if (dtype == STLLM_BF16) hipLaunchKernelGGL(attn_decode_single_kernel<bf16_t>, dim3(H, B), dim3(64 * kDecWaves), 0, stream, p);
+    else hipLaunchKernelGGL(attn_decode_single_kernel<f16_t>, dim3(H, B), dim3(64 * kDecWaves), 0, stream, p);
+    STLLM_CHECK_LAUNCH("stllm_attention_decode(single)");
+    return STLLM_OK;
+  }
   float* ws = reinterpret_cast<float*>(workspace);
   const int kps = (Skv + nsplit - 1) / nsplit;
   if (dtype == STLLM_BF16) {

@@ -14,7 +14,7 @@ void stllm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* stllm_last_error(void) { return g_err; }
-extern "C" int stllm_abi_version(void) { return 1; }
+extern "C" int stllm_abi_version(void) { return 2; }   // 2: stllm_gemm_args gained the trailing a_norm_* fields (round 2)
 
 static thread_local const char* g_last_kernel = "";
 void stllm_set_last_kernel(const char* name) { g_last_kernel = name; }

@@ -925,7 +925,12 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
     const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
-    // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench_before.log)
+    // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
+    if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
+      const int rc = a->epilogue != STLLM_EPI_PATCH ? stllm_gemv_launch(a->dtype, a->epilogue, p, stream) : STLLM_ERR_UNSUPPORTED;
+      if (rc == STLLM_ERR_UNSUPPORTED) stllm_set_error("stllm_gemm(a_norm): shape outside the decode regime (M=%d N=%d K=%d): run stllm_rmsnorm first", p.M, p.N, p.K);
+      return rc;
+    }
     if (p.M <= (gemv_mode == 1 ? 4 : 8) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
@@ -976,6 +981,10 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
     STLLM_CHECK_ARG(a->K == 588 && a->M % 256 == 0 && a->frames && a->aux0, "stllm_gemm(PATCH): need K=588, M=n_frames*256, frames, pos_embed");
     K = ((588 + panel - 1) / panel) * panel;
     STLLM_CHECK_ARG(a->ldw >= K, "stllm_gemm(PATCH): W must be zero-padded to ldw >= %d", K);
+  } else if (a->a_norm_x) {
+    STLLM_CHECK_ARG(a->dtype != STLLM_F32 && a->M <= 8 && a->a_norm_gamma && aligned16(a->a_norm_x) && aligned16(a->a_norm_gamma) &&
+                        a->a_norm_ldx >= a->K && a->a_norm_ldx % 4 == 0 && a->K % panel == 0 && a->a_rows_per_batch == 0,
+                    "stllm_gemm(a_norm): the fused RMSNorm operand needs a 16-bit dtype, M <= 8, flat 16-byte aligned fp32 rows (M=%d)", a->M);
   } else {
     STLLM_CHECK_ARG(a->A && aligned16(a->A), "stllm_gemm: A null or not 16-byte aligned");
     STLLM_CHECK_ARG(a->K % panel == 0, "stllm_gemm: K=%d must be a multiple of %d", a->K, panel);
@@ -1006,6 +1015,7 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   if (g_debug < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); g_debug = e ? atoi(e) : 0; }
   p.debug = g_debug;
   p.ws = reinterpret_cast<char*>(a->workspace); p.ws_bytes = a->workspace_bytes;
+  p.nx = a->a_norm_x; p.nx_ld = a->a_norm_ldx; p.ngamma = a->a_norm_gamma; p.neps = a->a_norm_eps;
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
   p.o_rpb = a->o_rows_per_batch; p.o_bs = a->o_batch_stride;
   switch (a->dtype) {
@@ -1030,12 +1040,15 @@ extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_)
 
 extern "C" int64_t stllm_gemm_workspace_bytes(void) { return kSkFlagBytes + (int64_t)256 * 256 * 256 * 4; }  // = 512 slabs of 128x128 too
 
+void stllm_attention_set_decode_single(int on);   // attention.hip
+
 extern "C" int stllm_set_option(const char* key, int value) {
   if (!key) return STLLM_ERR_BAD_SHAPE;
   if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4")) { g_w4_mode = value; return STLLM_OK; }
+  if (!strcmp(key, "attn_decode_single")) { stllm_attention_set_decode_single(value); return STLLM_OK; }
   if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;

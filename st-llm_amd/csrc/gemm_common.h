@@ -22,6 +22,7 @@ struct GemmParams {
   int a_rpb; int64_t a_bs_b;       // A 2-level rows: rows per batch, batch stride (bytes)
   int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
   int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
+  const float* nx; int64_t nx_ld; const float* ngamma; float neps;   // GEMV only: A := RMSNorm(nx) * ngamma (fp32 rows, stride nx_ld elements)
 };
 
 constexpr int kRowBytes = 128;  // one K panel row

@@ -41,13 +41,43 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmParams p) {
   const int K = p.K;
   const int row_bytes = K * 2;
   // ---- stage A (2-level row indexing honoured) -------------------------------------------------------------------
-  for (int m = 0; m < MR; ++m) {
-    int gr = m < p.M ? m : p.M - 1;
-    int64_t off = (int64_t)gr * p.lda_b;
-    if (p.a_rpb > 0) { const int bb = gr / p.a_rpb; off = (int64_t)bb * p.a_bs_b + (int64_t)(gr - bb * p.a_rpb) * p.lda_b; }
-    const char* src = p.A + off;
-    for (int c = tid * 16; c < row_bytes; c += 256 * 16)
-      *reinterpret_cast<i32x4*>(smem + m * row_bytes + c) = *reinterpret_cast<const i32x4*>(src + c);
+  if (p.nx) {
+    // A := RMSNorm(x) * gamma, computed here (Llama's input / post-attention norm fused into the projection of the decode step):
+    // same arithmetic as norm_row_kernel<T, true> (variance in fp32 over the row, (x * rstd) * gamma, one rounding to T).  Every
+    // workgroup recomputes it for the <= 8 rows — 16-32 KB of L2 reads against the weight panel it then streams from HBM.
+    __shared__ float red[8];
+    const int nvec = K >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(p.ngamma);
+    for (int m = 0; m < MR; ++m) {
+      const int gr = m < p.M ? m : p.M - 1;
+      const float4* xr = reinterpret_cast<const float4*>(p.nx + (int64_t)gr * p.nx_ld);
+      float ss = 0.0f;
+      for (int c = tid; c < nvec; c += 256) {
+        const float4 v = xr[c];
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) red[(m & 1) * 4 + wave] = ss;      // two slots: row m + 1 may write while a slow wave still reads row m's
+      __syncthreads();
+      ss = red[(m & 1) * 4] + red[(m & 1) * 4 + 1] + red[(m & 1) * 4 + 2] + red[(m & 1) * 4 + 3];
+      const float rstd = rsqrtf(ss / (float)K + p.neps);
+      for (int c = tid; c < nvec; c += 256) {
+        const float4 v = xr[c], g = g4[c];
+        uint2 pk;
+        pk.x = Elem<T>::pack2(v.x * rstd * g.x, v.y * rstd * g.y);
+        pk.y = Elem<T>::pack2(v.z * rstd * g.z, v.w * rstd * g.w);
+        *reinterpret_cast<uint2*>(smem + m * row_bytes + c * 8) = pk;
+      }
+    }
+  } else {
+    for (int m = 0; m < MR; ++m) {
+      int gr = m < p.M ? m : p.M - 1;
+      int64_t off = (int64_t)gr * p.lda_b;
+      if (p.a_rpb > 0) { const int bb = gr / p.a_rpb; off = (int64_t)bb * p.a_bs_b + (int64_t)(gr - bb * p.a_rpb) * p.lda_b; }
+      const char* src = p.A + off;
+      for (int c = tid * 16; c < row_bytes; c += 256 * 16)
+        *reinterpret_cast<i32x4*>(smem + m * row_bytes + c) = *reinterpret_cast<const i32x4*>(src + c);
+    }
   }
   __syncthreads();
 
@@ -193,7 +223,8 @@ int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStrea
   if (p.M < 1 || p.M > 8) return STLLM_ERR_UNSUPPORTED;
   const int mr = p.M <= 2 ? p.M : (p.M + 1) / 2 * 2;
   if (p.N % 64 || p.K % 8 || (int64_t)mr * p.K * 2 > 150 * 1024) return STLLM_ERR_UNSUPPORTED;
-  if ((p.lda_b % 16) || (p.ldw_b % 16)) return STLLM_ERR_UNSUPPORTED;
+  if ((!p.nx && (p.lda_b % 16)) || (p.ldw_b % 16)) return STLLM_ERR_UNSUPPORTED;
+  if (p.nx && (p.K % 4 || p.nx_ld % 4 || p.a_rpb > 0)) return STLLM_ERR_UNSUPPORTED;
   if (dtype == STLLM_BF16) return dispatch_gemv<bf16_t>(epilogue, p, stream);
   if (dtype == STLLM_F16) return dispatch_gemv<f16_t>(epilogue, p, stream);
   return STLLM_ERR_UNSUPPORTED;

@@ -43,7 +43,8 @@ class GemmArgs(ctypes.Structure):
                 ("rope_seq", c_int), ("rope_cols", c_int), ("M", c_int), ("N", c_int), ("K", c_int),
                 ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64),
+                ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")
@@ -243,8 +244,10 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None):
-    """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded)."""
+         a_rows=None, o_rows=None, a_norm=None):
+    """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
+    a_norm=(x, gamma, eps) with a=None (decode regime, M <= 8, 16-bit dtypes): the A operand is RMSNorm(x) * gamma of the fp32
+    rows x [M,K], computed inside the kernel (stllm_hip.h: a_norm_*)."""
     td = torch_dtype(dtype)
     args = GemmArgs()
     args.dtype, args.epilogue, args.act, args.out_is_f32 = dtype_code(td), epilogue, act, int(out_f32)
@@ -255,6 +258,13 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         _req(frames, torch.float32, "frames"); _req(pos_embed, torch.float32, "pos_embed")
         args.frames, args.aux0 = _p(frames), _p(pos_embed)
         args.A, args.lda = None, 0
+    elif a_norm is not None:
+        xn, gamma, eps = a_norm
+        _req(xn, torch.float32, "a_norm x"); _req(gamma, torch.float32, "a_norm gamma")
+        K = xn.shape[-1]
+        M = xn.shape[0] if M is None else M
+        args.A, args.lda = None, 0
+        args.a_norm_x, args.a_norm_ldx, args.a_norm_gamma, args.a_norm_eps = _p(xn), xn.stride(-2), _p(gamma), float(eps)
     else:
         _req(a, td, "A")
         K = a.shape[-1]

@@ -16,6 +16,8 @@ buffer of every layer IS the cache — ``KVCache`` owns one [B, max_len, 3*D] bu
 rows [0, len] in place: no copies, no re-layout.  Decode reuses the prefill kernels (small-M tiles); GEMV-regime kernels
 are future work.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -82,6 +84,9 @@ class KVCache:
         self.max_len, self.batch, self.hidden = max_len, batch, hidden
         self.qkv = [torch.empty((batch, max_len, 3 * hidden), device=device, dtype=dtype) for _ in range(n_layers)]
         self.len = 0
+
+
+FUSE_NORM_ROWS = int(os.environ.get("STLLM_DECODE_FUSE_ROWS", "2"))   # decode steps with at most this many rows fuse RMSNorm into the GEMVs
 
 
 class LlamaModel(nn.Module):
@@ -178,17 +183,28 @@ class LlamaModel(nn.Module):
         cpos, spos = cos[pos:pos + 1], sin[pos:pos + 1]
         x = x_new.reshape(B, D).float().clone()
         ML3 = cache.max_len * 3 * D
+        # 16-bit modes, <= 8 rows: both RMSNorms ride inside the GEMV that consumes them (2 launches per layer fewer)
+        # (every workgroup of the GEMV recomputes the norm of all its rows: worth it for 1-2 rows — 3.70 -> 3.29 ms/token —, a loss for
+        #  the 5 rows of beam search, where 2752 workgroups x 6 staged rows re-read 0.5 GB through L2)
+        fuse = dt != torch.float32 and B <= FUSE_NORM_ROWS
         for li_, pk in enumerate(layers):
-            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
             row = cache.qkv[li_][:, pos]                                   # [B, 3D] view, row stride max_len*3D
-            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cpos, spos), rope_seq=1, rope_cols=2 * D, out=row)
+            if fuse:
+                hip.gemm(None, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cpos, spos), rope_seq=1, rope_cols=2 * D, out=row,
+                         a_norm=(x, pk["ln1"], cfg.rms_norm_eps))
+            else:
+                h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
+                hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cpos, spos), rope_seq=1, rope_cols=2 * D, out=row)
             full = cache.qkv[li_].view(B * cache.max_len, 3 * D)
             a = hip.attention(row[:, :D], full[:, D:2 * D], full[:, 2 * D:], B=B, H=H, Sq=1, Skv=pos + 1, D=hd,
                               scale=hd ** -0.5, causal=False, q_strides=(ML3, 3 * D), k_strides=(ML3, 3 * D),
                               v_strides=(ML3, 3 * D))
             hip.gemm(a, pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
-            h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
-            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            if fuse:
+                g = hip.gemm(None, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU, a_norm=(x, pk["ln2"], cfg.rms_norm_eps))
+            else:
+                h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
+                g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
         cache.len = pos + 1
         h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)

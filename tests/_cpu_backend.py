@@ -29,8 +29,12 @@ def _rows(t, n, rows):
 
 
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
-         rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None, a_rows=None, o_rows=None):
+         rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None, a_rows=None, o_rows=None, a_norm=None):
     td = torch_dtype(dtype)
+    if a_norm is not None:   # fused RMSNorm operand of the decode regime (stllm_hip.h: a_norm_*)
+        xn, gamma, eps = a_norm
+        assert a is None and xn.shape[0] <= 8 and td != torch.float32
+        a = rmsnorm(xn, gamma, eps, dtype=dtype)[0]
     wf = w.float()
     N = w.shape[0]
     if epilogue == EPI_PATCH:

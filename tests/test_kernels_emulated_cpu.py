@@ -297,6 +297,28 @@ def test_gemv_rows_up_to_eight(dtype, M):
         close(cases[n], want[n], tol, f"gemv M={M} {n}")
 
 
+@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 1), (torch.float16, 5)])
+def test_gemv_with_fused_rmsnorm_operand(dtype, M):
+    """decode step: A := RMSNorm(x) * gamma computed inside the GEMV (a_norm_* of stllm_gemm_args) == rmsnorm kernel + GEMV"""
+    N, K = 128, 576
+    x = rnd(M, K, seed=60, scale=1.7)
+    gamma = rnd(K, seed=61) + 1.0
+    w = rnd(N, K, seed=62, dtype=dtype, scale=0.05)
+    resid = rnd(M, N, seed=63)
+    with _hipemu.emulated() as hip:
+        h, _ = hip.rmsnorm(x, gamma, 1e-6, dtype=dtype)
+        two = hip.gemm(h, w, dtype=dtype, epilogue=C.EPI_SWIGLU)
+        one = hip.gemm(None, w, dtype=dtype, epilogue=C.EPI_SWIGLU, a_norm=(x, gamma, 1e-6))
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel")
+        r1 = hip.gemm(None, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone(), a_norm=(x, gamma, 1e-6))
+        big = rnd(9, K, seed=64)
+        with pytest.raises(RuntimeError, match="a_norm"):
+            hip.gemm(None, w, dtype=dtype, a_norm=(big, gamma, 1e-6))
+    close(one, two, TOL[dtype], "fused rmsnorm + gemv vs the two launches")
+    close(one, C.gemm(None, w, dtype=dtype, epilogue=C.EPI_SWIGLU, a_norm=(x, gamma, 1e-6)), TOL[dtype], "fused rmsnorm + gemv vs contract")
+    close(r1, C.gemm(None, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone(), a_norm=(x, gamma, 1e-6)), 2e-5 * 50, "fused rmsnorm resid")
+
+
 # ---- forward streaming kernels (norm.hip, elementwise.hip; parity-green on the device): CPU regression net for future edits ----
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -474,9 +496,11 @@ def test_scale_rows(dtype):
 
 
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+@pytest.mark.parametrize("single", [1, 0])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_emulated_split_kv_decode_attention(dtype):
-    """the one-token decode step's attention (split-KV partial + merge kernels) on a strided KV cache layout == contract"""
+def test_emulated_split_kv_decode_attention(dtype, single):
+    """the one-token decode step's attention (single-pass kernel: one workgroup per head; split-KV partial + merge kernels) on a
+    strided KV cache layout == contract"""
     B, H, D, Skv, ML = 2, 2, 128, 100, 128                       # cache rows [B, ML, 3*H*D]; 100 keys in use
     HD = H * D
     cache = rnd(B * ML, 3 * HD, seed=120, dtype=dtype, scale=0.6)
@@ -485,7 +509,11 @@ def test_emulated_split_kv_decode_attention(dtype):
               v_strides=(ML * 3 * HD, 3 * HD))
     want = C.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
     with _hipemu.emulated() as hip:
-        got = hip.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
+        hip.set_option("attn_decode_single", single)
+        try:
+            got = hip.attention(row[:, :HD], cache[:, HD:2 * HD], cache[:, 2 * HD:], **kw)
+        finally:
+            hip.set_option("attn_decode_single", 1)
         assert hip._decode_attn
     close(got, want, 2 * TOL[dtype], "decode attention")
 

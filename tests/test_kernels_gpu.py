@@ -517,10 +517,12 @@ def test_gemv_decode_regime(hip, dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,H,Skv", [(1, 32, 580), (2, 4, 1), (3, 2, 47), (1, 8, 2048), (2, 3, 97)])
-def test_attention_decode_split_kv(hip, dtype, B, H, Skv):
-    """one-token decode against a KV cache laid out like LlamaModel's (fused [B, max_len, 3*H*128] buffer): the split-KV
-    kernel vs fp64 softmax(q K^T / sqrt(d)) V and vs the tile kernel it replaces"""
+@pytest.mark.parametrize("single", [1, 0])
+@pytest.mark.parametrize("B,H,Skv", [(1, 32, 580), (2, 4, 1), (3, 2, 47), (1, 8, 2048), (2, 3, 97), (5, 32, 601), (1, 4, 1536), (1, 4, 1537)])
+def test_attention_decode_split_kv(hip, dtype, B, H, Skv, single):
+    """one-token decode against a KV cache laid out like LlamaModel's (fused [B, max_len, 3*H*128] buffer): the single-pass
+    kernel (one workgroup per head, Skv <= 1536) and the split-KV pair vs fp64 softmax(q K^T / sqrt(d)) V and vs the tile kernel"""
+    hip.set_option("attn_decode_single", single)
     D, max_len = 128, Skv + 5
     td = hip.torch_dtype(dtype)
     cache, c64 = rnd("kvcache", (B * max_len, 3 * H * D), dtype)
@@ -541,6 +543,32 @@ def test_attention_decode_split_kv(hip, dtype, B, H, Skv):
     finally:
         hip._decode_attn = True
     check(got, tile.double().cpu(), 2 * OUT_TOL[dtype], "decode attention vs tile kernel")
+    hip.set_option("attn_decode_single", 1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M", [1, 5])
+def test_gemv_fused_rmsnorm_operand(hip, dtype, M):
+    """decode step: Llama's RMSNorm fused into the GEMV that consumes it (stllm_gemm_args.a_norm_*): same numbers as the
+    rmsnorm kernel followed by the GEMV, and fp64-close; rejected outside the decode regime"""
+    from stllm_amd import pack
+    K, I = 4096, 1024
+    x = T("nx", (M, K), 1.7).cuda()
+    gamma = (T("ngamma", (K,), 0.2) + 1.0).cuda()
+    wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+    wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+    wgu = pack.llama_gate_up(wg, wu, dtype)
+    h16, _ = hip.rmsnorm(x, gamma, 1e-6, dtype=dtype)
+    two = hip.gemm(h16, wgu, dtype=dtype, epilogue=hip.EPI_SWIGLU)
+    one = hip.gemm(None, wgu, dtype=dtype, epilogue=hip.EPI_SWIGLU, a_norm=(x, gamma, 1e-6))
+    assert "gemv_kernel" in hip.lib().stllm_last_kernel().decode()
+    assert (one.float() - two.float()).abs().max().item() <= 2e-2 * two.float().abs().max().item()
+    x64 = x.double().cpu()
+    hn = (gamma.double().cpu() * x64 * torch.rsqrt((x64 ** 2).mean(-1, keepdim=True) + 1e-6))
+    hn = hn.to(hip.torch_dtype(dtype)).double()
+    check(one, F.silu(hn @ wg64.t()) * (hn @ wu64.t()), OUT_TOL[dtype], "fused rmsnorm gemv swiglu vs fp64")
+    with pytest.raises(RuntimeError, match="a_norm"):
+        hip.gemm(None, wgu, dtype=dtype, epilogue=hip.EPI_SWIGLU, a_norm=(T("nx9", (9, K), 1.0).cuda(), gamma, 1e-6))
 
 
 def test_gemm_rejects_bad_shapes(hip):

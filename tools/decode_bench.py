@@ -12,7 +12,8 @@ ap.add_argument("--vit-depth", type=int, default=1)
 ap.add_argument("--qformer-layers", type=int, default=1)
 ap.add_argument("--tokens", type=int, default=16)
 ap.add_argument("--rows", type=int, default=1, help="sequences decoded together (5 = demo.py's beam search)")
-ap.add_argument("--gemv", type=int, default=-1, help="stllm_set_option('gemm_gemv'): -1 default (M <= 4), 0 off, 2 = up to M = 8")
+ap.add_argument("--gemv", type=int, default=-1, help="stllm_set_option('gemm_gemv'): -1 default (M <= 8), 1 = M <= 4, 0 off")
+ap.add_argument("--attn-single", type=int, default=1, help="stllm_set_option('attn_decode_single')")
 args = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
@@ -21,6 +22,7 @@ lm = model.model
 S = 576
 from stllm_amd import hip
 hip.set_option("gemm_gemv", args.gemv)
+hip.set_option("attn_decode_single", args.attn_single)
 R = args.rows
 emb = (torch.randn(1, S, 4096, device=dev) * 0.02).expand(R, S, 4096).contiguous()
 cache = lm.new_cache(R, S + args.tokens + 8, dev)
@@ -36,4 +38,4 @@ for _ in range(args.tokens):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.tokens * 1e3
 wbytes = sum(p.numel() for n, p in lm.named_parameters() if "layers" in n) * 2 + 32000 * 4096 * 2
-print(f"decode ({R} rows, gemm_gemv {args.gemv}): {ms:.2f} ms/step ({1e3 / ms:.1f} tok/s), weights streamed per token {wbytes / 1e9:.2f} GB => {wbytes / ms / 1e9:.2f} TB/s")
+print(f"decode ({R} rows, gemm_gemv {args.gemv}, attn_single {args.attn_single}, fuse_norm_rows {os.environ.get('STLLM_DECODE_FUSE_ROWS', '2')}): {ms:.2f} ms/step ({1e3 / ms:.1f} tok/s), weights streamed per token {wbytes / 1e9:.2f} GB => {wbytes / ms / 1e9:.2f} TB/s")

@@ -67,6 +67,13 @@ int main(int argc, char** argv) {
       {"dp2_192", 3072, 8192, 1408, STLLM_EPI_STORE, 0, 0},       // 512 tiles of 192 x 256: two whole rounds, no remainder
       {"dp2_192g", 3072, 8192, 1408, STLLM_EPI_STORE, 1, 0},      // ... with the GELU epilogue
       {"dp1_192", 3072, 4096, 1408, STLLM_EPI_STORE, 0, 0},       // 256 tiles of 192 x 256: one round
+      // Q-Former at T = 16 (16 frames x 32 queries = 512 rows): self-attention qkv / out, FFN, cross-attention K|V of one layer / all six
+      {"qf_qkv", 512, 2304, 768, STLLM_EPI_STORE, 0, 0},
+      {"qf_out", 512, 768, 768, STLLM_EPI_STORE, 0, 1},
+      {"qf_ffn1", 512, 3072, 768, STLLM_EPI_STORE, 1, 0},
+      {"qf_ffn2", 512, 768, 3072, STLLM_EPI_STORE, 0, 1},
+      {"qf_xkv1", 4112, 1536, 1408, STLLM_EPI_STORE, 0, 0},
+      {"qf_xkv6", 4112, 9216, 1408, STLLM_EPI_STORE, 0, 0},
       // training step, 16 clips x 576 tokens = 9216 rows: dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T) with fp32 output
       {"tr_dgrad_down", 9216, 11008, 4096, STLLM_EPI_STORE, 0, 0},
       {"tr_dgrad_gu", 9216, 4096, 22016, STLLM_EPI_STORE, 0, 0},
