@@ -130,7 +130,7 @@ def _free_port():
     return p
 
 
-def _fp_worker(rank, world, port, cfg_name, q):
+def _fp_worker(rank, world, port, cfg_names, q):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for pth in (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here):
@@ -140,50 +140,58 @@ def _fp_worker(rank, world, port, cfg_name, q):
     torch.set_num_threads(2)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from stllm_amd import runtime
-    cfg = CFGS[cfg_name]
-    model = build(cfg)
-    samples, _ = make_inputs(3, 2, cfg["qformer_text_input"])     # 3 clips x 2 frames on 2 ranks: ragged 3/3 frame split, clips 0,2 | 1
-    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
-        single = model(samples=samples).logits.clone()             # 1-process result (no sharding)
-        model.model.stllm_model.set_frame_parallel(rank, world)
-        out = model(samples=samples)
-    own = model.model.stllm_model.owned_clips
-    q.put((rank, own, out.logits.clone(), single))
+    from stllm_amd import runtime, synth
+    from stllm_amd.tokenizer import IdTokenizer
+    IdTokenizer.hf_special_tokens = False   # as tests/conftest.py (spawned workers do not run it)
+    synth.enable_cache()                    # the second model reuses the LLM tensors generated for the first
+    for cfg_name in cfg_names:
+        cfg = CFGS[cfg_name]
+        model = build(cfg)
+        samples, _ = make_inputs(3, 2, cfg["qformer_text_input"])     # 3 clips x 2 frames on 2 ranks: clips 0,2 | 1 (frame ranges levelled against that load)
+        with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+            single = model(samples=samples).logits.clone()             # 1-process result (no sharding)
+            model.model.stllm_model.set_frame_parallel(rank, world)
+            out = model(samples=samples)
+        own = model.model.stllm_model.owned_clips
+        q.put((cfg_name, rank, own, out.logits.clone(), single))
+        del model
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cfg_name", ["instructblip_residual_text", "btadapter", "minigpt4_mask_mvm"])
-def test_frame_parallel_model_matches_single_process(cfg_name):
-    """N=2 ranks: frames sharded, ONE all-gather, each rank prefills the clips it owns — logits bit-identical to the
-    unsharded run for those clips (the all-gather moves bits; every kernel sees the same rows in the same order).
-    BT-Adapter backbone: whole clips per rank (its temporal attention couples the frames of a clip), no collective."""
-    if cfg_name == "minigpt4_mask_mvm":
-        pytest.skip("masking draws from the numpy RNG per rank; the injected-mask variant is covered on the GPU")
+def test_frame_parallel_model_matches_single_process():
+    """N=2 ranks: frames sharded, ONE all-gather, each rank prefills the clips it owns — logits equal to the unsharded run for
+    those clips (the all-gather moves bits; every kernel sees the same rows in the same order).  BT-Adapter backbone: whole clips per
+    rank (its temporal attention couples the frames of a clip), no collective.  Both backbones in ONE pair of worker processes
+    (model building dominates the cost).  (minigpt4_mask_mvm draws its mask from the numpy RNG per rank: the injected-mask
+    variant is covered on the GPU.)"""
     world = 2
+    cfg_names = ["instructblip_residual_text", "btadapter"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_fp_worker, args=(r, world, port, cfg_name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_fp_worker, args=(r, world, port, cfg_names, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(world)]
+    res = [q.get(timeout=900) for _ in range(world * len(cfg_names))]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    seen = []
-    for rank, own, logits, single in res:
-        assert own == [c for c in range(3) if c % world == rank]
-        seen += own
-        # the sharded run pads to the longest sequence among the OWNED clips only: compare the common prefix of valid rows
-        S = logits.shape[1]
-        for j, c in enumerate(own):
-            a, b = logits[j], single[c, :S] if single.shape[1] >= S else single[c]
-            n = min(a.shape[0], b.shape[0])
-            # (the contract backend's CPU BLAS blocks a 1-clip and a 3-clip GEMM differently: a few fp32 ulps, not bits)
-            assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 5e-5, f"rank {rank} clip {c}"
-    assert sorted(seen) == [0, 1, 2]
+    for cfg_name in cfg_names:
+        seen = []
+        for name, rank, own, logits, single in res:
+            if name != cfg_name:
+                continue
+            assert own == [c for c in range(3) if c % world == rank]
+            seen += own
+            # the sharded run pads to the longest sequence among the OWNED clips only: compare the common prefix of valid rows
+            S = logits.shape[1]
+            for j, c in enumerate(own):
+                a, b = logits[j], single[c, :S] if single.shape[1] >= S else single[c]
+                n = min(a.shape[0], b.shape[0])
+                # (the contract backend's CPU BLAS blocks a 1-clip and a 3-clip GEMM differently: a few fp32 ulps, not bits)
+                assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 5e-5, f"{cfg_name}: rank {rank} clip {c}"
+        assert sorted(seen) == [0, 1, 2], cfg_name
 
 
 def test_chat_upload_raw_frames_on_host_graph():
