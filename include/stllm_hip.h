@@ -116,13 +116,15 @@ int stllm_gemm_workspace_status(const void* workspace, void* stream);
  * for tile_rows = 192 | 256; heavy = 0 plain 16-bit output, 1 fp32 output / residual, 2 GELU.  T = q * 256 + r tiles of
  * tile_rows x 256; the s workgroups of a remainder tile sit on one XCD (s <= 32, 8 * cap >= r, cap = 32 / s). */
 int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
-/* The same for the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc): shape = 34 (192 x 256 tile) | 44 (256 x 256). */
+/* The same for the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc): shape = 32 (192 x 128 tile) | 42 (256 x 128) | 34 (192 x 256) |
+ * 44 (256 x 256).  heavy bit 3 (| 8): the epilogue is STORE / RESID, so a last tile row of <= 32 rows is computed outside the tile
+ * grid ("thin tail": ViT fc1's 4112 rows = 16 tile rows + 16 rows) and does not count as tiles. */
 int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
 /* tuning / test hooks:
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_w4"    = -1 auto (currently: never) | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
- *                  other kernels' estimates | 32 / 34 / 44 always, 192 x 128 / 192 x 256 / 256 x 256 tile:
+ *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
+ *                  other kernels' estimates | 32 / 42 / 34 / 44 always, 192 x 128 / 256 x 128 / 192 x 256 / 256 x 256 tile:
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 8) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernel of the decode regime (st-llm_amd/csrc/gemv.hip);
  *                  M <= 8 covers the 5 beams of demo.py's beam search (6.99 -> 6.02 ms per 5-row step on MI355X)

@@ -905,14 +905,13 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
   int split = 1;
   const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape, &split);
-  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44) { *shape = g_w4_mode; return true; }
+  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42) { *shape = g_w4_mode; return true; }
   if (g_w4_mode == 1) return true;
   if (g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_p8_mode == 0) return false;   // a forced / disabled kernel family (tests / experiments) wins
-  // Measured inside bench.py (cold weights every launch, unlike the harness's warm repeats): proj + fc2 on the 192 x 128 w4 tile
-  // 5.39 ms per step against 5.46 ms on the phased / 128x128 kernels — no gain once the weights come from HBM (the 2-deep LDS
-  // ring prefetches one unit ahead; the phased kernel's loads have two phases more to land).  The automatic choice therefore
-  // stays off until the ring is deeper; STLLM_GEMM_W4=2 (or stllm_set_option("gemm_w4", 2)) enables the rule below.
-  if (g_w4_mode != 2) return false;
+  // Round 2, first version (2-buffer LDS ring): no gain inside bench.py, where the weights come from HBM (proj + fc2 5.39 ms per
+  // step against 5.46 ms); with the 3-buffer ring of the 192 x 128 tile the harness measures the same time on cold weights as on
+  // warm ones (tools/gemm_harness ... <cold MiB>, profiles/r02_w4_ring3.md) and the rule below is the default (-1 == 2).
+  if (g_w4_mode != 2 && g_w4_mode != -1) return false;
   if (split != 1 || p.M < 1024) return false;
   const float other = p8_est_us < old_kernels_estimate_us(p) ? p8_est_us : old_kernels_estimate_us(p);
   return est < 0.97f * other;
@@ -924,7 +923,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): -1 / 2 = GEMV up to M = 8 (the 5 beams of demo.py), 1 = up to M = 4, 0 = off
     if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
     if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
-    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44;   // tests / experiments
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
     if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
       const int rc = a->epilogue != STLLM_EPI_PATCH ? stllm_gemv_launch(a->dtype, a->epilogue, p, stream) : STLLM_ERR_UNSUPPORTED;
@@ -942,7 +941,8 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     if (a->epilogue != STLLM_EPI_PATCH) {
       int shape = 44, miw2 = 4;
       const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2);
-      if (w4_wanted(p, heavy, &shape, p8_est)) {
+      const int thin_bit = (a->epilogue == STLLM_EPI_STORE || a->epilogue == STLLM_EPI_RESID) ? 8 : 0;   // gemm_w4.inc: thin tail rows allowed
+      if (w4_wanted(p, heavy | thin_bit, &shape, p8_est)) {
         const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
                                                       : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
         if (rc != STLLM_ERR_UNSUPPORTED) return rc;

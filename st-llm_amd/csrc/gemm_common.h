@@ -23,6 +23,7 @@ struct GemmParams {
   int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
   int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
   const float* nx; int64_t nx_ld; const float* ngamma; float neps;   // GEMV only: A := RMSNorm(nx) * ngamma (fp32 rows, stride nx_ld elements)
+  int w4_thin;                     // gemm_w4 only: the last M % tile_rows (<= 32) rows are computed outside the tile grid (0 = none)
 };
 
 constexpr int kRowBytes = 128;  // one K panel row

@@ -366,15 +366,17 @@ def test_gemm_bench_shapes_auto_dispatch(hip, M, N, K, kind):
     assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
 
 
-W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7), (2100, 2944, 256), (3072, 2048, 704)]
+W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 256, 6144), (1, 128, 128 * 7), (2100, 2944, 256), (3072, 2048, 704),
+             (528, 768, 1408), (596, 384, 256)]   # the last two: a tail of 16 rows past 256-row tiles / 20 rows past 192-row tiles (thin-tail path)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 44])
+@pytest.mark.parametrize("shape", [32, 34, 44, 42])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 def test_gemm_w4(hip, dtype, shape, M, N, K):
-    """one-wave-per-SIMD kernel forced on (192 x 256 and 256 x 256 tiles): whole rounds, remainder-first K-split with the
-    end-of-launch reduction, M / N tails, fp32 / GELU / residual epilogues, epoch flags, determinism."""
+    """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128 tiles): whole rounds, remainder-first K-split
+    with the end-of-launch reduction, M / N tails (incl. the thin-tail rows computed outside the tile grid), fp32 / GELU / residual
+    epilogues, epoch flags, determinism."""
     hip.set_option("gemm_w4", shape)
     try:
         a, a64 = rnd("a", (M, K), dtype, 0.5)

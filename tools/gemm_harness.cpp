@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
   const int p8opt = argc > 4 ? atoi(argv[4]) : 1;   // 1: cost model picks the tile height, 3 / 4: force 192 / 256 rows
   const int w4opt = argc > 5 ? atoi(argv[5]) : 0;   // 0: test the phased kernel; 1 / 34 / 44: test the one-wave-per-SIMD kernel (gemm_w4)
   const int baseopt = argc > 6 ? atoi(argv[6]) : 0; // baseline ("old" column): 0 = 128x128 kernels, 1 = phased kernel (cost model)
+  const int cold_mb = argc > 7 ? atoi(argv[7]) : 0; // > 0: the timed loop rotates over copies of W worth this many MiB (weights come from HBM, as in the model)
   std::vector<Case> cases = {
       {"tiny_store", 256, 256, 128, STLLM_EPI_STORE, 0, 0},
       {"edge_store", 300, 384, 192, STLLM_EPI_STORE, 0, 0},
@@ -126,6 +127,17 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dcos, hcos.data(), hcos.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dsin, hsin.data(), hsin.size() * 4, hipMemcpyHostToDevice));
 
+    std::vector<void*> dWs;   // cold-weight mode: more copies of W than the 256 MiB of MALL hold
+    if (cold_mb > 0) {
+      const size_t wb = hW.size() * 2;
+      const int n = (int)(((size_t)cold_mb << 20) / wb) + 2;
+      for (int i = 0; i < n; ++i) {
+        void* q;
+        CK(hipMalloc(&q, wb));
+        CK(hipMemcpy(q, dW, wb, hipMemcpyDeviceToDevice));
+        dWs.push_back(q);
+      }
+    }
     stllm_gemm_args a;
     memset(&a, 0, sizeof(a));
     a.dtype = STLLM_BF16; a.epilogue = c.epi; a.act = c.act; a.out_is_f32 = c.of32;
@@ -172,9 +184,13 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
       }
       CK(hipEventRecord(e0, st));
-      for (int r = 0; r < reps; ++r) stllm_gemm(&a, st);
+      for (int r = 0; r < reps; ++r) {
+        if (!dWs.empty()) a.W = dWs[r % dWs.size()];
+        stllm_gemm(&a, st);
+      }
       CK(hipEventRecord(e1, st));
       CK(hipStreamSynchronize(st));
+      a.W = dW;
       float ms;
       CK(hipEventElapsedTime(&ms, e0, e1));
       *us = ms * 1000.0f / reps;
@@ -257,6 +273,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
     if (rc0 || rc1 || nbad) ++bad;
     hipFree(dA); hipFree(dA2); hipFree(dW); hipFree(db); hipFree(dres); hipFree(dcos); hipFree(dsin); hipFree(dout0); hipFree(dout1); hipFree(dfirst);
+    for (void* q : dWs) hipFree(q);
     if (rc1 == -100) break;
   }
   printf("%s\n", bad ? "HARNESS FAIL" : "HARNESS OK");
