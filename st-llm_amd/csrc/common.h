@@ -197,6 +197,32 @@ __device__ __forceinline__ float gelu_poly16(float x) {
   phi = x < -4.3f ? 0.0f : phi;
   return x * phi;
 }
+// two values at once on the packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per instruction): 17
+// instructions per pair instead of 28; bit-identical to gelu_poly16 on each element
+typedef __attribute__((ext_vector_type(2))) float stllm_f32x2;
+__device__ __forceinline__ void gelu_poly16_x2(float& x0, float& x1) {
+  const stllm_f32x2 x = {x0, x1};
+  stllm_f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x0, -4.3f, 4.3f);
+  xc[1] = __builtin_amdgcn_fmed3f(x1, -4.3f, 4.3f);
+  const stllm_f32x2 t = xc * xc;
+  auto c = [](float v) { stllm_f32x2 r = {v, v}; return r; };
+  stllm_f32x2 p = c(5.1581142135326274e-11f);
+  p = __builtin_elementwise_fma(p, t, c(-5.033940375653856e-09f));
+  p = __builtin_elementwise_fma(p, t, c(2.1685210072064365e-07f));
+  p = __builtin_elementwise_fma(p, t, c(-5.490918738360051e-06f));
+  p = __builtin_elementwise_fma(p, t, c(9.222461812896654e-05f));
+  p = __builtin_elementwise_fma(p, t, c(-0.00110264727845788f));
+  p = __builtin_elementwise_fma(p, t, c(0.009800615720450878f));
+  p = __builtin_elementwise_fma(p, t, c(-0.06632684171199799f));
+  p = __builtin_elementwise_fma(p, t, c(0.3988965153694153f));
+  stllm_f32x2 phi = __builtin_elementwise_fma(xc, p, c(0.5f));
+  phi[0] = x0 < -4.3f ? 0.0f : phi[0];
+  phi[1] = x1 < -4.3f ? 0.0f : phi[1];
+  const stllm_f32x2 y = x * phi;
+  x0 = y[0];
+  x1 = y[1];
+}
 __device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
