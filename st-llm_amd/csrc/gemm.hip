@@ -930,7 +930,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       if (rc == STLLM_ERR_UNSUPPORTED) stllm_set_error("stllm_gemm(a_norm): shape outside the decode regime (M=%d N=%d K=%d): run stllm_rmsnorm first", p.M, p.N, p.K);
       return rc;
     }
-    if (p.M <= (gemv_mode == 1 ? 4 : 8) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {
+    if (p.M <= (gemv_mode == 1 ? 4 : 16) && a->epilogue != STLLM_EPI_PATCH && gemv_mode != 0 && !forced_tiles) {   // 9..16 rows: matrix-core GEMV only (gemv.hip)
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
     }
@@ -1048,6 +1048,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4")) { g_w4_mode = value; return STLLM_OK; }
+  if (!strcmp(key, "gemv_mfma")) { stllm_gemv_set_mfma(value); return STLLM_OK; }
   if (!strcmp(key, "attn_decode_single")) { stllm_attention_set_decode_single(value); return STLLM_OK; }
   if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);

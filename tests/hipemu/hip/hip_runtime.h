@@ -52,6 +52,8 @@ inline float emu_med3(float a, float b, float c) { return std::max(std::min(a, b
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32<8>(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32(a, b, c)
 #define __builtin_amdgcn_fmed3f(a, b, c) emu_med3(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, n, o, a) emu_global_load_lds(g, l, n, o)
 #define __builtin_amdgcn_readfirstlane(x) (x)
@@ -125,6 +127,29 @@ template <int KPL, typename VA, typename VC> inline VC emu_mfma_32x32(VA a, VA b
   }
   return c;
 }
+// v_mfma_f32_16x16x32_{f16,bf16}: D[16x16] += A[16x32] B[32x16]; lane l holds 8 k values of A row l%16 and of B column l%16 for
+// k-group l/16 (which 8 of the 32 does not matter: A and B use the same grouping); D register j of lane l is D[4*(l/16) + j][l%16].
+template <typename VA, typename VC> inline VC emu_mfma_16x16x32(VA a, VA b, VC c) {
+  const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
+  const int ph = (emu_phase ^= 1) * 8 * emu_cur->n;
+  float* A = emu_cur->ma.data() + ph;
+  float* B = emu_cur->mb.data() + ph;
+  for (int e = 0; e < 8; ++e) { A[8 * t + e] = (float)a[e]; B[8 * t + e] = (float)b[e]; }
+  emu_cur->wave[t >> 6]->arrive_and_wait();
+  const int n = lane & 15;
+  for (int j = 0; j < 4; ++j) {
+    const int m = 4 * (lane / 16) + j;
+    float acc = c[j];
+    for (int g = 0; g < 4; ++g)
+      for (int e = 0; e < 8; ++e) acc += A[8 * (w0 + m + 16 * g) + e] * B[8 * (w0 + n + 16 * g) + e];
+    c[j] = acc;
+  }
+  return c;
+}
+// v_dot2c_f32_{bf16,f16}: c + a[0] * b[0] + a[1] * b[1]
+template <typename V2> inline float emu_fdot2(V2 a, V2 b, float c) { return c + ((float)a[0] * (float)b[0] + (float)a[1] * (float)b[1]); }
+#define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp) emu_fdot2(a, b, c)
+#define __builtin_amdgcn_fdot2(a, b, c, clamp) emu_fdot2(a, b, c)
 template <typename VC> inline VC emu_mfma_32x32_f32(float a, float b, VC c) {   // 32x32x2: lane l holds A[l%32][l/32], B[l/32][l%32]
   const int t = threadIdx.x, lane = t & 63, w0 = t & ~63;
   const int ph = (emu_phase ^= 1) * 8 * emu_cur->n;

@@ -265,8 +265,8 @@ def test_emulated_forward_attention_matches_contract(dtype, shape):
 
 
 # ---- skinny GEMM of the decode regime, incl. the staged M = 5..8 extension (beam search: 5 beams) -----------------------------
-@pytest.mark.parametrize("dtype,M", [(torch.bfloat16, 5), (torch.float16, 8)])
-def test_gemv_rows_up_to_eight(dtype, M):
+@pytest.mark.parametrize("dtype,M,mfma", [(torch.bfloat16, 5, 0), (torch.float16, 8, 0), (torch.bfloat16, 5, -1), (torch.float16, 12, -1)])
+def test_gemv_rows_up_to_eight(dtype, M, mfma):
     from stllm_amd import pack
     N, K = 128, 576                                    # K % 512 != 0: one full 1024-byte step + a ragged one; K % 64 == 0 (stllm_gemm)
     a = rnd(M, K, seed=50, dtype=dtype, scale=0.5)
@@ -275,7 +275,8 @@ def test_gemv_rows_up_to_eight(dtype, M):
     resid = rnd(M, N, seed=53)
     cos, sin = pack.rope_tables(4, 128)
     with _hipemu.emulated() as hip:
-        hip.set_option("gemm_gemv", 2)                  # the real dispatch of stllm_gemm: GEMV kernel up to M = 8
+        hip.set_option("gemm_gemv", 2)                  # the real dispatch of stllm_gemm: GEMV kernels up to M = 16
+        hip.set_option("gemv_mfma", mfma)               # 0: the VALU kernel (M <= 8); -1: the matrix-core kernel from M = 3
         try:
             cases = {
                 "store": hip.gemm(a, w, dtype=dtype, bias=bias),
@@ -283,9 +284,10 @@ def test_gemv_rows_up_to_eight(dtype, M):
                 "swiglu": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_SWIGLU),
                 "rope": hip.gemm(a, w, dtype=dtype, epilogue=C.EPI_ROPE, rope=(cos[1:2], sin[1:2]), rope_seq=1, rope_cols=128),
             }
-            assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel"), hip.lib().stllm_last_kernel()
+            assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel" if mfma == 0 else "gemv_mfma_kernel"), hip.lib().stllm_last_kernel()
         finally:
             hip.set_option("gemm_gemv", -1)
+            hip.set_option("gemv_mfma", -1)
     want = {
         "store": C.gemm(a, w, dtype=dtype, bias=bias),
         "resid": C.gemm(a, w, dtype=dtype, epilogue=C.EPI_RESID, resid=resid.clone()),
@@ -546,7 +548,7 @@ def test_generate_on_emulated_kernels():
             hip.set_option("gemm_gemv", 2)          # demo.py's num_beams = 5 on the staged M <= 8 GEMV (MR = 6)
             try:
                 got5 = model.generate(inputs_embeds=emb, max_new_tokens=2, num_beams=5, eos_token_id=None)
-                assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel")
+                assert hip.lib().stllm_last_kernel().decode().startswith("gemv_")     # 5 beams: the matrix-core GEMV
             finally:
                 hip.set_option("gemm_gemv", -1)
     close(got_logits, want_logits, 2.0 ** -6, "prefill logits")

@@ -465,20 +465,39 @@ def test_gemm_phased_auto_dispatch(hip):
     assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()   # no split-K exchange of this process ever timed out
 
 
+def _gemv_kernel_expected(M, K, mfma):
+    """which kernel family stllm_gemm picks in the decode regime (gemv.hip: stllm_gemv_launch)"""
+    if mfma != 0 and M >= (1 if mfma == 1 else 3) and K % 64 == 0:
+        return "gemv_mfma_kernel<"
+    mr = M if M <= 2 else (M + 1) // 2 * 2
+    if M <= 8 and mr * K * 2 <= 150 * 1024:
+        return "gemv_kernel<"
+    return "gemm"       # the staged rows of A do not fit the LDS: the tile kernels
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("M,mfma", [(1, -1), (2, -1), (3, -1), (4, -1), (5, -1), (8, -1), (12, -1), (16, -1), (3, 0), (5, 0), (8, 0), (1, 1), (2, 1)])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (256, 11008), (1536, 704)])
-def test_gemv_decode_regime(hip, dtype, M, N, K):
-    """skinny kernel of the decode regime (M <= 8 by default since round 2: the 5 beams of demo.py; gemv.hip): every epilogue against fp64, K tails (K % 512 != 0), strided output rows"""
+def test_gemv_decode_regime(hip, dtype, M, N, K, mfma):
+    """skinny kernels of the decode regime (gemv.hip; M <= 16 since round 2: the 5 beams of demo.py, small serving batches): the VALU
+    kernel (M <= 2 by default) and the matrix-core kernel (M >= 3): every epilogue against fp64, K tails (K % 512 != 0), strided
+    output rows, the LDS-fit fallbacks"""
+    from stllm_amd import pack
+    hip.set_option("gemv_mfma", mfma)
+    try:
+        _gemv_decode_regime(hip, dtype, M, N, K, _gemv_kernel_expected(M, K, mfma))
+    finally:
+        hip.set_option("gemv_mfma", -1)
+
+
+def _gemv_decode_regime(hip, dtype, M, N, K, want):
     from stllm_amd import pack
     a, a64 = rnd("a", (M, K), dtype, 0.5)
     w, w64 = rnd("w", (N, K), dtype, 0.05)
     b = T("b", (N,), 0.5)
     ref = a64 @ w64.t() + b.double()
     out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
-    mr = M if M <= 2 else (M + 1) // 2 * 2
-    fits = mr * K * 2 <= 160 * 1024      # the staged rows of A live in LDS; beyond that stllm_gemm falls back to the tile kernels
-    assert hip.lib().stllm_last_kernel().decode().startswith("gemv_kernel<") == fits, hip.lib().stllm_last_kernel().decode()
+    assert hip.lib().stllm_last_kernel().decode().startswith(want), (hip.lib().stllm_last_kernel().decode(), want)
     check(out, ref, ACC_TOL[dtype], "gemv store f32")
     check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "gemv gelu T")
     x = T("x", (M, N), 2.0)
@@ -495,7 +514,7 @@ def test_gemv_decode_regime(hip, dtype, M, N, K):
         wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
         wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
         o = hip.gemm(a, pack.llama_gate_up(wg, wu, dtype), dtype=dtype, epilogue=hip.EPI_SWIGLU)
-        assert "gemv_kernel" in hip.lib().stllm_last_kernel().decode()
+        assert hip.lib().stllm_last_kernel().decode().startswith(want)
         check(o, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "gemv swiglu")
         H, D = N // 3 // 128, 128
         if H >= 1 and H * 3 * 128 == N:
