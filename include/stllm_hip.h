@@ -126,8 +126,10 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
  *                  other kernels' estimates | 32 / 42 / 34 / 44 always, 192 x 128 / 256 x 128 / 192 x 256 / 256 x 256 tile:
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_gemv"  = -1 on (M <= 8) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernel of the decode regime (st-llm_amd/csrc/gemv.hip);
- *                  M <= 8 covers the 5 beams of demo.py's beam search (6.99 -> 6.02 ms per 5-row step on MI355X)
+ *   "gemm_gemv"  = -1 on (M <= 16) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernels of the decode regime (st-llm_amd/csrc/gemv.hip):
+ *                  the 5 beams of demo.py's beam search, small serving batches (5-row step 6.99 -> 4.34 ms on MI355X)
+ *   "gemv_mfma"  = -1 matrix-core GEMV (v_mfma_f32_16x16x32) from M = 3, the VALU kernel (v_dot2c) below | 0 never (M > 8 then runs on the
+ *                  tile kernels) | 1 from M = 1
  *   "attn_decode_single" = 1 (default) one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
