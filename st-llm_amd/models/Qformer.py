@@ -139,7 +139,16 @@ class BertModel(nn.Module):
         fp = params_fingerprint(self.encoder.layer.parameters())
         hit = self._packed.get(dt)
         if hit is None or hit[0] != fp:
-            hit = (fp, [l.pack(dt) for l in self.encoder.layer])
+            layers = [l.pack(dt) for l in self.encoder.layer]
+            # the cross-attention K/V projections of ALL layers read the same image tokens: one [n_cross * 2C, 1408] weight, one GEMM
+            # per forward instead of one per cross layer (6 launches of 4112 x 1536 x 1408 -> 1 of 4112 x 9216 x 1408 at config 2)
+            cross = [pk for pk in layers if "ckv_w" in pk]
+            if cross:
+                w_all = torch.cat([pk["ckv_w"] for pk in cross], dim=0).contiguous()
+                b_all = torch.cat([pk["ckv_b"] for pk in cross], dim=0).contiguous()
+                for j, pk in enumerate(cross):
+                    pk["ckv_all"] = (w_all, b_all, j, len(cross))
+            hit = (fp, layers)
             self._packed = {dt: hit}
         return hit[1]
 
@@ -183,6 +192,7 @@ class BertModel(nn.Module):
         rows_q = dict(M=n * Q, o_rows=(Q, S * 3 * C)) if Lt else {}
         rows_t = dict(M=n * Lt, o_rows=(Lt, S * 3 * C)) if Lt else {}
         hd = C // H
+        ckv_all = None
         for i, pk in enumerate(layers):
             # ---- self-attention over [queries | text] (Qformer.py:417-424) -------------------------
             hip.gemm(hq16, pk["wqkv"], dtype=dt, bias=pk["bqkv"], out=qkv, **rows_q)
@@ -197,7 +207,10 @@ class BertModel(nn.Module):
             # ---- cross-attention, query rows only, even layers (Qformer.py:430-444) -----------------
             if "cq_w" in pk:
                 cq = hip.gemm(hq16, pk["cq_w"], dtype=dt, bias=pk["cq_b"])
-                ckv = hip.gemm(enc16, pk["ckv_w"], dtype=dt, bias=pk["ckv_b"])
+                w_all, b_all, j, n_cross = pk["ckv_all"]
+                if ckv_all is None:
+                    ckv_all = hip.gemm(enc16, w_all, dtype=dt, bias=b_all)
+                ckv = ckv_all[:, j * 2 * C:(j + 1) * 2 * C]
                 cctx = hip.attention(cq, ckv[:, :C], ckv[:, C:], B=n, H=H, Sq=Q, Skv=P, D=hd, scale=1.0 / math.sqrt(hd))
                 hq32, hq16 = _post_ln(cctx, pk["cross_out"], hq32, dt)
             # ---- FFN: query rows -> *_query weights, text rows -> text weights (Qformer.py:449-462) ----
