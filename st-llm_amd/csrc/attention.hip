@@ -254,20 +254,38 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
     const int n_tiles = (win_keys + 31) >> 5;
     if (win0 > 0) __syncthreads();   // previous window fully consumed
     // ---- stage this window's K and V^T (rows >= Skv and dims >= D are zero) ------------------------------
-    for (int ch = tid; ch < n_tiles * 32 * CPR; ch += blockDim.x) {
-      const int t = ch / (32 * CPR), rem = ch - t * (32 * CPR);
-      const int cc = rem >> 5, lrow = t * 32 + (rem & 31);
-      const int row = win0 + lrow;
-      const bool ok = (row < p.Skv) && (cc * 8 < D);
-      i32x4 z = {0, 0, 0, 0};
-      const i32x4 kv_ = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)row * p.k_rs + cc * 8) * 2) : z;
-      const i32x4 vv = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)row * p.v_rs + cc * 8) * 2) : z;
-      *reinterpret_cast<i32x4*>(k_lds + lrow * KPITCH + cc * 16) = kv_;
+    // kStageUn chunks per thread are requested before the first one is written: the staging pass pays ONE memory round trip per
+    // group instead of one per chunk (ViT: 3456 chunks of K and of V over 576 threads = 6 per thread)
+    constexpr int kStageUn = 3;
+    const int n_chunks = n_tiles * 32 * CPR;
+    for (int ch0 = tid; ch0 < n_chunks; ch0 += blockDim.x * kStageUn) {
+      i32x4 kq[kStageUn], vq[kStageUn];
+      int lrow_[kStageUn], cc_[kStageUn];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t w = (uint32_t)vv[e];
-        *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + lrow * 2) = (uint16_t)(w & 0xffff);
-        *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + lrow * 2) = (uint16_t)(w >> 16);
+      for (int u = 0; u < kStageUn; ++u) {
+        const int ch = ch0 + u * (int)blockDim.x;
+        const int chc = ch < n_chunks ? ch : n_chunks - 1;
+        const int t = chc / (32 * CPR), rem = chc - t * (32 * CPR);
+        const int cc = rem >> 5, lrow = t * 32 + (rem & 31);
+        const int row = win0 + lrow;
+        const bool ok = (ch < n_chunks) && (row < p.Skv) && (cc * 8 < D);
+        const i32x4 z = {0, 0, 0, 0};
+        kq[u] = ok ? *reinterpret_cast<const i32x4*>(kbase + ((int64_t)row * p.k_rs + cc * 8) * 2) : z;
+        vq[u] = ok ? *reinterpret_cast<const i32x4*>(vbase + ((int64_t)row * p.v_rs + cc * 8) * 2) : z;
+        lrow_[u] = lrow;
+        cc_[u] = cc;
+      }
+#pragma unroll
+      for (int u = 0; u < kStageUn; ++u) {
+        if (ch0 + u * (int)blockDim.x >= n_chunks) break;
+        const int lrow = lrow_[u], cc = cc_[u];
+        *reinterpret_cast<i32x4*>(k_lds + lrow * KPITCH + cc * 16) = kq[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t w = (uint32_t)vq[u][e];
+          *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e) * VPITCH + lrow * 2) = (uint16_t)(w & 0xffff);
+          *reinterpret_cast<uint16_t*>(v_lds + (cc * 8 + 2 * e + 1) * VPITCH + lrow * 2) = (uint16_t)(w >> 16);
+        }
       }
     }
     __syncthreads();
