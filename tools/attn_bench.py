@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stllm_amd import hip
 
-CASES = [("vit", 16, 16, 257, 257, 88, False, 39), ("llama", 1, 32, 576, 576, 128, True, 32),
+CASES = [("vit", 16, 16, 257, 257, 88, False, 39), ("llama", 1, 32, 576, 576, 128, True, 32), ("llama_b4", 4, 32, 576, 576, 128, True, 32),
          ("qf_self", 16, 12, 32, 32, 64, False, 12), ("qf_cross", 16, 12, 32, 257, 64, False, 6)]
 for name, B, H, Sq, Skv, D, causal, per_clip in CASES:
     dt = torch.bfloat16
