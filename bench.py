@@ -59,7 +59,17 @@ def build_model(device, args, model_cfg=None):
                llama_model=dict(num_hidden_layers=args.llm_layers))
     cfg.update(model_cfg or {})
     model = st_llm.STLLMForCausalLM.from_config(cfg, device=device)
-    synth.fill_module_(model, 0, "")
+    if getattr(args, "dry_cpu", False):
+        # plumbing check on CPU: the values do not matter, the integer-hash generator (bit-identical on CPU and GPU, ~40 s for the
+        # full-width tensors on a host core) does cost — every rank draws the same numbers from the same torch seed instead
+        g = torch.Generator().manual_seed(1234)
+        with torch.no_grad():
+            for name, t in model.named_parameters():
+                if torch.is_floating_point(t):
+                    mean, std = synth._rule(name)
+                    t.copy_(torch.randn(t.shape, generator=g) * std + mean)
+    else:
+        synth.fill_module_(model, 0, "")
     return model.eval()
 
 

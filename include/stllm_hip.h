@@ -53,6 +53,10 @@ typedef enum { STLLM_ACT_NONE = 0, STLLM_ACT_GELU = 1, STLLM_ACT_RELU = 2 } stll
 
 const char* stllm_last_error(void);
 int stllm_abi_version(void);
+/* HOST utility (no GPU involved): n values of the deterministic synthetic-weight stream (stllm_amd/synth.py: random-init benchmarks,
+ * parity fixtures) for element indices start .. start + n - 1 of the tensor whose (name, seed) hash to `key`; bit-identical to the
+ * torch recipe that fills device tensors. */
+int stllm_synth_normal_f32(float* out, int64_t n, int64_t start, uint32_t key, float scale, float mean);
 /* name of the kernel template instantiation chosen by the last stllm_gemm call on this thread (for profiling) */
 const char* stllm_last_kernel(void);
 

@@ -1,6 +1,10 @@
 // thread-local last-error string + ABI version for libstllm_hip.so
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
+
+#include <thread>
+#include <vector>
 
 #include "../../include/stllm_hip.h"
 
@@ -19,3 +23,40 @@ extern "C" int stllm_abi_version(void) { return 2; }   // 2: stllm_gemm_args gai
 static thread_local const char* g_last_kernel = "";
 void stllm_set_last_kernel(const char* name) { g_last_kernel = name; }
 extern "C" const char* stllm_last_kernel(void) { return g_last_kernel; }
+
+// ---- host side of the synthetic-weight generator (stllm_amd/synth.py) -----------------------------------------------------------
+// out[i] = ((bytesum(a) + bytesum(b)) - 1020) * scale (+ mean), a = hash32((start + i) ^ key), b = hash32(a + 0x68E31DA4 + start + i):
+// exactly the integer recipe synth.normal_ runs with torch ops (on the GPU for the product, on the CPU for the oracle / fixtures) —
+// the torch version manages ~20 M elements/s on a host core, which made the CPU test-suite spend most of its time generating
+// the same full-width tensors; this loop does ~1 G/s.  Exact integer ops + one IEEE multiply (+ one add): bit-identical.
+static inline uint32_t synth_hash32(uint32_t x) {
+  x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+  x = ((x >> 16) ^ x) * 0x45D9F3Bu;
+  return (x >> 16) ^ x;
+}
+static inline uint32_t synth_bytesum(uint32_t u) { return (u & 0xFF) + ((u >> 8) & 0xFF) + ((u >> 16) & 0xFF) + (u >> 24); }
+
+extern "C" int stllm_synth_normal_f32(float* out, int64_t n, int64_t start, uint32_t key, float scale, float mean) {
+  if (!out || n < 0 || start < 0) { stllm_set_error("stllm_synth_normal_f32: bad arguments"); return STLLM_ERR_BAD_SHAPE; }
+  auto work = [=](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
+      const uint64_t idx = (uint64_t)(start + i);
+      const uint32_t a = synth_hash32((uint32_t)((idx ^ (uint64_t)key) & 0xFFFFFFFFull));
+      const uint32_t b = synth_hash32((uint32_t)(((uint64_t)a + 0x68E31DA4ull + idx) & 0xFFFFFFFFull));
+      const float z = (float)(int)(synth_bytesum(a) + synth_bytesum(b)) - 1020.0f;
+      float v = z * scale;
+      if (mean != 0.0f) v = v + mean;
+      out[i] = v;
+    }
+  };
+  const int nt = n >= (1 << 22) ? 8 : 1;
+  if (nt == 1) { work(0, n); return STLLM_OK; }
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+    if (lo < hi) th.emplace_back(work, lo, hi);
+  }
+  for (auto& t : th) t.join();
+  return STLLM_OK;
+}

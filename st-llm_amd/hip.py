@@ -19,7 +19,7 @@ _DT = {torch.bfloat16: BF16, torch.float16: F16, torch.float32: F32}
 _NAMES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32,
           "bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}
 
-EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
+EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_synth_normal_f32", "stllm_gemm", "stllm_layernorm", "stllm_rmsnorm",
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
            "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_gemm_w4_plan", "stllm_set_option",
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
@@ -67,6 +67,7 @@ def _bind(L, strict=True):
     B("stllm_last_error", None, c_char_p)
     B("stllm_abi_version")
     B("stllm_last_kernel", None, c_char_p)
+    B("stllm_synth_normal_f32", [c_void_p, c_int64, c_int64, ctypes.c_uint32, c_float, c_float])
     B("stllm_gemm", [ctypes.POINTER(GemmArgs), c_void_p])
     B("stllm_layernorm", [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p])
     B("stllm_rmsnorm", [c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p])

@@ -44,6 +44,20 @@ def name_key(name: str, seed: int) -> int:
     return (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & _M32
 
 
+def _host_fill(flat, n, key, scale, mean) -> bool:
+    """CPU fp32 tensors: the same stream from the C loop in libstllm_hip.so (stllm_synth_normal_f32, ~50x the torch recipe on a host
+    core; bit-identical — tests/test_host_cpu.py).  False when the library is not built: the torch recipe below takes over."""
+    try:
+        import ctypes
+        from . import hip
+        import numpy as np
+        # scale / mean as torch would apply them: the python floats rounded to fp32
+        rc = hip.lib().stllm_synth_normal_f32(ctypes.c_void_p(flat.data_ptr()), n, 0, key, float(np.float32(scale)), float(np.float32(mean)))
+        return rc == 0
+    except Exception:
+        return False
+
+
 def normal_(t: torch.Tensor, name: str, seed: int = 0, std: float = 0.02, mean: float = 0.0) -> torch.Tensor:
     """Fill `t` in place (any float dtype, any device) from (name, seed)."""
     global _CACHE_BYTES
@@ -57,6 +71,11 @@ def normal_(t: torch.Tensor, name: str, seed: int = 0, std: float = 0.02, mean: 
             flat.copy_(hit)
             return t
     scale = std / 209.02152999054  # sqrt(8 * (256^2 - 1) / 12)
+    if t.device.type == "cpu" and t.dtype == torch.float32 and flat.is_contiguous() and _host_fill(flat, n, key, scale, mean):
+        if _CACHE is not None and _CACHE_BYTES + 4 * n <= _CACHE_LIMIT:
+            _CACHE[ck] = flat.clone()
+            _CACHE_BYTES += 4 * n
+        return t
     for s in range(0, n, _CHUNK):
         e = min(n, s + _CHUNK)
         idx = torch.arange(s, e, dtype=torch.int64, device=t.device)

@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--dry-cpu", "--steps", "1", "--warmup", "1", "--vit-depth", "1", "--qformer-layers", "2", "--llm-layers", "1", "--frames", "2"]
+SMALL = ["--dry-cpu", "--steps", "1", "--warmup", "0", "--vit-depth", "1", "--qformer-layers", "2", "--llm-layers", "1", "--frames", "2"]
 
 
 def _run(extra, timeout=900):

@@ -249,3 +249,24 @@ def test_id_tokenizer_contract():
     assert tk("###Human: 9 10 ###", add_special_tokens=True).input_ids.tolist() == [[1, 9, 10]]
     assert tk(["1 2 3 4"], truncation=True, max_length=2, add_special_tokens=False).input_ids.tolist() == [[1, 2]]
     assert tk("", add_special_tokens=False).input_ids.shape == (1, 0)
+
+
+def test_synth_host_generator_is_bit_identical_to_the_torch_recipe():
+    """stllm_synth_normal_f32 (error.cpp) is what fills CPU tensors since round 2; the torch recipe (the one that fills device
+    tensors) must give the same bits: (name, seed) keys, chunk boundaries of the threaded loop, non-zero mean, tiny tensors."""
+    from stllm_amd import synth
+    saved = synth._CACHE
+    synth._CACHE = None
+    try:
+        for n, std, mean in [(1, 0.02, 0.0), (4097, 1.0, 0.5), ((1 << 22) + 13, 0.02, 0.0), (3 * 1408 * 64, 1e-3, -2.0)]:
+            a, b = torch.empty(n), torch.empty(n)
+            synth.normal_(a, "model.layers.0.mlp.down_proj.weight", 7, std, mean)
+            host = synth._host_fill
+            synth._host_fill = lambda *k: False
+            try:
+                synth.normal_(b, "model.layers.0.mlp.down_proj.weight", 7, std, mean)
+            finally:
+                synth._host_fill = host
+            assert torch.equal(a, b), (n, std, mean)
+    finally:
+        synth._CACHE = saved

@@ -19,7 +19,7 @@ from _util import T, sd_from
 torch.set_grad_enabled(False)
 
 
-def build(cfg, vit_depth=1, qf_layers=2, llm_layers=1):
+def build(cfg, vit_depth=1, qf_layers=2, llm_layers=1, llm=None):
     from stllm_amd import synth
     from stllm_amd.models import st_llm
     from stllm_amd.models.blip2 import Blip2Base
@@ -28,7 +28,7 @@ def build(cfg, vit_depth=1, qf_layers=2, llm_layers=1):
     Blip2Base.vit_depth, Blip2Base.qformer_layers = vit_depth, qf_layers
     Blip2Base.init_tokenizer = classmethod(lambda cls, truncation_side="right": IdTokenizer(0, 1, 2, 32000))
     try:
-        m = st_llm.STLLMForCausalLM.from_config(dict(cfg, llama_model=dict(num_hidden_layers=llm_layers)), device="cpu")
+        m = st_llm.STLLMForCausalLM.from_config(dict(cfg, llama_model=dict(num_hidden_layers=llm_layers, **(llm or {}))), device="cpu")
     finally:
         Blip2Base.vit_depth, Blip2Base.qformer_layers, Blip2Base.init_tokenizer = old
     synth.fill_module_(m, 0, "")
@@ -137,7 +137,7 @@ def _fp_worker(rank, world, port, cfg_names, q):
         if pth not in sys.path:
             sys.path.insert(0, pth)
     torch.set_grad_enabled(False)
-    torch.set_num_threads(2)
+    torch.set_num_threads(4)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from stllm_amd import runtime, synth
@@ -173,7 +173,12 @@ def test_frame_parallel_model_matches_single_process():
     procs = [ctx.Process(target=_fp_worker, args=(r, world, port, cfg_names, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in range(world * len(cfg_names))]
+    res = []
+    while len(res) < world * len(cfg_names):      # a worker that died must fail the test, not hang it
+        try:
+            res.append(q.get(timeout=10))
+        except Exception:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

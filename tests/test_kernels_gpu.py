@@ -337,7 +337,7 @@ def test_gemm_phased_swiglu_rope_rows(hip, miw):
 
 
 BENCH_SHAPES = [(4112, 6144, 1408, "gelu"), (4112, 1408, 6144, "resid"), (4112, 4224, 1408, "store"), (4112, 1408, 1408, "resid"),
-                (576, 12288, 4096, "store"), (576, 4096, 11008, "resid")]
+                (576, 12288, 4096, "store"), (576, 4096, 11008, "resid"), (576, 4096, 4096, "resid"), (576, 32000, 4096, "store")]
 
 
 @pytest.mark.parametrize("M,N,K,kind", BENCH_SHAPES)
