@@ -404,7 +404,63 @@ def test_gemm_w4(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 44])
+def test_gemm_w4_thin_tail_at_vit_fc1_size(hip):
+    """ViT fc1 at the benchmarked size on the 256 x 128 tile: 4112 rows = 16 tile rows (768 tiles = three whole rounds) + 16 thin
+    rows; GELU 16-bit output; fc2 on the same tile (176 tiles + thin rows on idle workgroups too); the thin rows are checked on
+    their own as well."""
+    M, N, K = 4112, 6144, 1408
+    assert hip.gemm_w4_plan(M, N, K, 2 | 8, 42)[:3] == (3, 0, 1)
+    hip.set_option("gemm_w4", 42)
+    try:
+        for dtype in ("bf16", "fp16"):
+            a, a64 = rnd("a", (M, K), dtype, 0.5)
+            w, w64 = rnd("w", (N, K), dtype, 0.05)
+            b = T("b", (N,), 0.5)
+            ref = (a64.cuda() @ w64.cuda().t() + b.double().cuda()).cpu()
+            out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU)
+            assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_w4_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},4,2,STORE,1,")
+            check(out, O.gelu(ref), OUT_TOL[dtype], "fc1 gelu")
+            check(out[4096:], O.gelu(ref[4096:]), OUT_TOL[dtype], "fc1 gelu, thin rows")
+            assert torch.equal(out, hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU)), "not bit-identical across launches"
+            wt, wt64 = rnd("w2", (1408, 6144), dtype, 0.05)
+            a2, a264 = rnd("a2", (M, 6144), dtype, 0.5)
+            x = T("x", (M, 1408), 2.0)
+            xd = x.cuda()
+            hip.gemm(a2, wt, dtype=dtype, epilogue=hip.EPI_RESID, resid=xd)
+            check(xd, (x.double().cuda() + a264.cuda() @ wt64.cuda().t()).cpu(), ACC_TOL[dtype], "fc2 resid")
+            check(xd[4096:], (x.double().cuda() + a264.cuda() @ wt64.cuda().t()).cpu()[4096:], ACC_TOL[dtype], "fc2 resid, thin rows")
+        assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+    finally:
+        hip.set_option("gemm_w4", -1)
+
+
+@pytest.mark.parametrize("shape,n_seq", [(42, 9), (32, 7), (34, 7), (44, 9)])
+def test_gemm_w4_thin_tail_with_two_level_rows(hip, shape, n_seq):
+    """the thin tail rows go through the same 2-level row addressing as the tiles (Q-Former row groups: A rows read from / out rows
+    written into a [n, S, C] buffer): n x 32 query rows = one full tile + 32 thin rows, fp32 output and the residual epilogue"""
+    S, Q, C, Nout = 44, 32, 768, 384
+    hip.set_option("gemm_w4", shape)
+    try:
+        for dtype in ("bf16", "fp16"):
+            buf, buf64 = rnd("buf", (n_seq * S, C), dtype)
+            w, w64 = rnd("w", (Nout, C), dtype, 0.05)
+            ref = buf64.view(n_seq, S, C)[:, :Q].reshape(-1, C) @ w64.t()
+            out = torch.zeros((n_seq * S, Nout), device="cuda", dtype=torch.float32)
+            hip.gemm(buf, w, dtype=dtype, out=out, out_f32=True, M=n_seq * Q, a_rows=(Q, S * C), o_rows=(Q, S * Nout))
+            assert "gemm_w4_kernel" in hip.lib().stllm_last_kernel().decode()
+            o = out.view(n_seq, S, Nout)
+            check(o[:, :Q].reshape(-1, Nout), ref, ACC_TOL[dtype], "query rows")
+            assert float(o[:, Q:].abs().max()) == 0.0, "rows outside the groups were written"
+            x = T("x", (n_seq * Q, Nout), 2.0)
+            xd = x.cuda()
+            hip.gemm(buf, w, dtype=dtype, epilogue=hip.EPI_RESID, resid=xd, M=n_seq * Q, a_rows=(Q, S * C))
+            check(xd, x.double() + ref, ACC_TOL[dtype], "query rows, residual")
+        assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+    finally:
+        hip.set_option("gemm_w4", -1)
+
+
+@pytest.mark.parametrize("shape", [32, 34, 44, 42])
 def test_gemm_w4_swiglu_rope_rows(hip, shape):
     from stllm_amd import pack
     dtype = "bf16"
