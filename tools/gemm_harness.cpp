@@ -69,7 +69,8 @@ int main(int argc, char** argv) {
       {"dp2_192g", 3072, 8192, 1408, STLLM_EPI_STORE, 1, 0},      // ... with the GELU epilogue
       {"dp1_192", 3072, 4096, 1408, STLLM_EPI_STORE, 0, 0},       // 256 tiles of 192 x 256: one round
       // Q-Former at T = 16 (16 frames x 32 queries = 512 rows): self-attention qkv / out, FFN, cross-attention K|V of one layer / all six
-      {"llm_qkv_store", 576, 12288, 4096, STLLM_EPI_STORE, 0, 0},   // the Llama qkv shape without the ROPE epilogue
+      {"llm_qkv_store", 576, 12288, 4096, STLLM_EPI_STORE, 0, 0},
+      {"llm_gu_255", 576, 21760, 4096, STLLM_EPI_SWIGLU, 0, 0},     // 255 tiles of 192 x 256: the gate/up GEMM without its 2 remainder tiles   // the Llama qkv shape without the ROPE epilogue
       {"qf_qkv", 512, 2304, 768, STLLM_EPI_STORE, 0, 0},
       {"qf_out", 512, 768, 768, STLLM_EPI_STORE, 0, 1},
       {"qf_ffn1", 512, 3072, 768, STLLM_EPI_STORE, 1, 0},
