@@ -19,6 +19,11 @@
 namespace {
 using namespace sg;
 
+// VALU kernel: the weights are read exactly once per launch, in whole 128-byte lines per instruction: non-temporal loads (decode
+// 3.23 -> 3.08 ms/token).  NOT in the matrix-core kernel, whose two loads per step touch the two halves of the same lines: there
+// the hint costs the second half its cache hit (5 beams: 4.34 -> 4.66 ms).
+__device__ __forceinline__ i32x4 ldw(const char* ptr) { return __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(ptr)); }
+
 template <typename T> __device__ __forceinline__ void widen8(i32x4 v, float* f);
 template <> __device__ __forceinline__ void widen8<bf16_t>(i32x4 v, float* f) {
 #pragma unroll
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmParams p) {
     for (int u = 0; u < kU; ++u) {
       const int kb = kbase + u * 1024 + lane_b;
       if (kb < row_bytes) {
-        wa[u] = *reinterpret_cast<const i32x4*>(w0 + kb);
-        wb[u] = *reinterpret_cast<const i32x4*>(w1 + kb);
+        wa[u] = ldw(w0 + kb);
+        wb[u] = ldw(w1 + kb);
       }
     }
   };
@@ -418,7 +423,7 @@ int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStrea
   if (p.M < 1 || p.M > 16) return STLLM_ERR_UNSUPPORTED;
   if (p.N % 64 || p.K % 8 || (p.ldw_b % 16) || (!p.nx && (p.lda_b % 16))) return STLLM_ERR_UNSUPPORTED;
   if (g_gemv_mfma == -2) { const char* e = getenv("STLLM_GEMV_MFMA"); g_gemv_mfma = e ? atoi(e) : -1; }
-  const int from = g_gemv_mfma == 0 ? 17 : g_gemv_mfma == 1 ? 1 : 3;
+  const int from = g_gemv_mfma == 0 ? 17 : g_gemv_mfma >= 1 ? g_gemv_mfma : 3;   // n >= 1: from M = n
   if (!p.nx && p.M >= from && p.K % 64 == 0) {
     if (dtype == STLLM_BF16) return dispatch_gemv_mfma<bf16_t>(epilogue, p, stream);
     if (dtype == STLLM_F16) return dispatch_gemv_mfma<f16_t>(epilogue, p, stream);
