@@ -332,9 +332,13 @@ def _run(args, world, rank, device, dry):
             counts = parallel.frame_counts(B * T, world, sm._prefill_load(B, T, world))
             res["frames_per_rank"] = counts     # levelled against the prefill load of each rank (stllm_amd.parallel.frame_counts)
             res["allgather_bytes_per_rank"] = max(counts) * 32 * 4096 * 4
+            # one clip per GPU: every rank's frames are the clip it prefills, the collective is skipped inside the step (allgather_us
+            # is the stand-alone timing of what it would cost)
+            res["allgather_in_step"] = bool(parallel.gather_needed(B * T, T, world, sm._prefill_load(B, T, world)))
             if conf["scaling"] == "weak":
                 res["scaling_note"] = ("c2 at N > 1 is weak scaling (one clip per GPU; each rank's frame range is its own clip, so the all-gather "
-                                       "carries no remote token the prefill needs); the frame-parallel experiment is --config c3 (strong scaling)")
+                                       "would carry no remote token the prefill needs and is skipped: allgather_in_step false); the frame-parallel "
+                                       "experiment is --config c3 (strong scaling)")
         if dry:
             res["data"] = "DRY RUN on CPU (gloo + tests/_cpu_backend.py): orchestration check, NOT a measurement"
         full = (args.vit_depth, args.qformer_layers, args.llm_layers, T) == (39, 12, 32, conf["frames"])

@@ -100,6 +100,7 @@ class STLLMModel(Blip2Base):
         self.max_txt_len, self.end_sym = max_txt_len, end_sym
         self.embed_tokens = None  # set by STLLMLlamaModel.initialize_vision_modules (st_llm.py:54)
         self.frame_parallel = None  # (rank, world, group): see stllm_amd.parallel
+        self._fp_local_clips = False
 
     def set_frame_parallel(self, rank, world, group=None):
         """Shard the work of a batch over `world` GPUs.  eva_clip_g: the per-frame encode is split into contiguous frame
@@ -156,7 +157,12 @@ class STLLMModel(Blip2Base):
                     all_t = [qtext] * frames.shape[0] if isinstance(qtext, str) else [t for t in qtext for _ in range(T)]
                     t_local = all_t[s0: s0 + fr.shape[0]]
                 return self._encode_frames(fr, t_local, T, dt)
-            tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load)
+            self._fp_local_clips = not parallel.gather_needed(frames.shape[0], T, world, load)
+            if self._fp_local_clips:   # this rank's frames ARE the clips it prefills (one clip per GPU): nothing to exchange
+                s0, e0 = parallel.frame_range(frames.shape[0], rank, world, load)
+                tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, 32, 4096), dtype=torch.float32, device=image.device)
+            else:
+                tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load)
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
             atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
             return inputs_llama, atts_llama, use_image
@@ -325,11 +331,12 @@ class STLLMModel(Blip2Base):
             # clip-parallel prefill: this rank continues with the clips it owns (clip c -> rank c % world)
             from .. import parallel
             rank, world, _ = self.frame_parallel
-            own = parallel.clips_of_rank(img_embeds.shape[0], rank, world)
+            own = parallel.clips_of_rank(image.shape[0], rank, world)
             self.owned_clips = own
             if not own:
                 return None
-            img_embeds = img_embeds[own].contiguous()
+            if not getattr(self, "_fp_local_clips", False):   # (skipped all-gather: img_embeds holds exactly the owned clips already)
+                img_embeds = img_embeds[own].contiguous()
             if instruction is not None and not isinstance(instruction, str):
                 instruction = [instruction[c] for c in own]
             answers_txt = [answers_txt[c] for c in own]

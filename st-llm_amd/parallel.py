@@ -14,7 +14,9 @@ SURVEY.md §2b); correctness criterion: the gathered token block is bit-identica
      speed-up at the ViT/LLM FLOP ratio, SURVEY.md §7 hard-part 3);
   4. with fewer clips than GPUs (config 3: 4 clips on 8 GPUs) the frame ranges are NOT equal: a rank that also prefills a clip
      gets fewer frames than a rank that does not (frame_counts: one prefill ~ 12 frames of encode at S = 576), so that all
-     ranks finish together — 26 / 38 frames instead of 32 / 32 in config 3 at N = 8.
+     ranks finish together — 26 / 38 frames instead of 32 / 32 in config 3 at N = 8;
+  5. when the frame ranges coincide with the clips every rank prefills (one clip per GPU: bench.py's weak-scaling config 2 at
+     N > 1) the all-gather would move 8.4 MB per rank that nobody reads: gather_needed() is False and the collective is skipped.
 """
 import torch
 import torch.distributed as dist
@@ -57,6 +59,19 @@ def frame_range(n_frames, rank, world, extra=None):
 
 def clips_of_rank(n_clips, rank, world):
     return [c for c in range(n_clips) if c % world == rank]
+
+
+def gather_needed(n_frames, T, world, extra=None):
+    """False when every rank's frame range is exactly the frames of the clips it prefills (clip c -> rank c % world): the all-gather
+    would then carry nothing any rank needs — the weak-scaling case of one clip per GPU — and is skipped.  Deterministic: every rank
+    computes the same answer, so either all of them enter the collective or none."""
+    n_clips = n_frames // T
+    for r in range(world):
+        s, e = frame_range(n_frames, r, world, extra)
+        for c in clips_of_rank(n_clips, r, world):
+            if c * T < s or (c + 1) * T > e:
+                return True
+    return False
 
 
 def all_gather_frames(local, n_frames, rank, world, group=None, extra=None):

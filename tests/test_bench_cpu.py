@@ -21,7 +21,7 @@ def _run(extra, timeout=900):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("config,scaling,batch", [("c3", "strong", 4)])   # (c2 at N = 2 runs the same rank code with B = N clips; ~70 s of model building saved)
+@pytest.mark.parametrize("config,scaling,batch", [("c3", "strong", 4), ("c2", "weak", 2)])
 def test_bench_self_spawns_two_ranks(config, scaling, batch):
     res = _run(["--gpus", "2", "--config", config])
     assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["config"]["name"] == config
@@ -30,6 +30,7 @@ def test_bench_self_spawns_two_ranks(config, scaling, batch):
     assert res["allgather_bytes_per_rank"] == (batch * 2 // 2) * 32 * 4096 * 4
     assert "frame-parallel x2" in res["config"]["parallelism"] and "DRY RUN" in res["data"]
     assert res["loss"] == res["loss"], "rank 0 owns clip 0: its loss must be a number"
+    assert res["allgather_in_step"] == (config == "c3")   # one clip per GPU (c2): the collective carries nothing and is skipped
     if config == "c3":
         assert res["config"]["video_tokens_per_clip"] == 2 * 32 and "residual" in res["config"]["workload"]   # R clamped to the 2 frames of the dry run
 

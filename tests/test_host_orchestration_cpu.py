@@ -154,6 +154,16 @@ def _fp_worker(rank, world, port, cfg_names, q):
             out = model(samples=samples)
         own = model.model.stllm_model.owned_clips
         q.put((cfg_name, rank, own, out.logits.clone(), single))
+        if cfg["vit_model"] == "eva_clip_g":
+            # one clip per rank: the frame ranges ARE the clips each rank prefills, the all-gather is skipped (parallel.gather_needed)
+            samples2, _ = make_inputs(2, 2, cfg["qformer_text_input"])
+            with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+                model.model.stllm_model.set_frame_parallel(0, 1)
+                single2 = model(samples=samples2).logits.clone()
+                model.model.stllm_model.set_frame_parallel(rank, world)
+                out2 = model(samples=samples2)
+            assert model.model.stllm_model._fp_local_clips
+            q.put((cfg_name + "/one_clip_per_rank", rank, model.model.stllm_model.owned_clips, out2.logits.clone(), single2))
         del model
     dist.barrier()
     dist.destroy_process_group()
@@ -174,7 +184,8 @@ def test_frame_parallel_model_matches_single_process():
     for p in procs:
         p.start()
     res = []
-    while len(res) < world * len(cfg_names):      # a worker that died must fail the test, not hang it
+    n_results = world * (len(cfg_names) + 1)      # + the one-clip-per-rank case of the eva_clip_g config
+    while len(res) < n_results:      # a worker that died must fail the test, not hang it
         try:
             res.append(q.get(timeout=10))
         except Exception:
@@ -197,6 +208,12 @@ def test_frame_parallel_model_matches_single_process():
                 # (the contract backend's CPU BLAS blocks a 1-clip and a 3-clip GEMM differently: a few fp32 ulps, not bits)
                 assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 5e-5, f"{cfg_name}: rank {rank} clip {c}"
         assert sorted(seen) == [0, 1, 2], cfg_name
+    extra = [r for r in res if r[0].endswith("/one_clip_per_rank")]
+    assert len(extra) == world
+    for name, rank, own, logits, single in extra:
+        assert own == [rank]
+        n = min(logits.shape[1], single.shape[1])
+        assert (logits[0, :n] - single[rank, :n]).abs().max() <= 5e-5, name
 
 
 def test_chat_upload_raw_frames_on_host_graph():

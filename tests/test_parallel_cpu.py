@@ -82,3 +82,15 @@ def test_frame_range_and_clip_ownership():
                 assert sum(c) == n and min(c) >= 0
                 lv = [c[k] + ex[k] for k in range(w) if c[k] > 0]
                 assert max(lv) - min(lv) <= 1.0 + 1e-9, (n, w, ex, c)    # levelled to within one frame among the ranks that got frames
+
+
+def test_gather_needed_only_when_a_rank_prefills_frames_it_did_not_encode():
+    from stllm_amd import parallel as P
+    # one clip per GPU (weak scaling): ranges == clips, nothing to exchange
+    for world in (2, 4, 8):
+        assert not P.gather_needed(world * 16, 16, world, [12.0] * world)
+        assert not P.gather_needed(world * 16, 16, world, None)
+    assert P.gather_needed(4 * 16, 16, 2, [24.0, 24.0])                            # 4 clips on 2 ranks: rank 0 prefills clips 0 and 2, encodes 0 and 1
+    assert P.gather_needed(4 * 64, 64, 8, [12.0] * 4 + [0.0] * 4)                  # config 3 on 8 GPUs: frames levelled, clips split
+    assert P.gather_needed(3 * 2, 2, 2, None)                                      # 3 clips on 2 ranks
+    assert not P.gather_needed(16, 16, 1, None)
