@@ -912,12 +912,12 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   // step against 5.46 ms); with the 3-buffer ring of the 192 x 128 tile the harness measures the same time on cold weights as on
   // warm ones (tools/gemm_harness ... <cold MiB>, profiles/r02_w4_ring3.md) and the rule below is the default (-1 == 2).
   if (g_w4_mode != 2 && g_w4_mode != -1) return false;
-  if (p.M < 512) return false;
+  // exchange-free plans only: the one candidate with a K-split that the estimates favour, the Llama qkv GEMM (576 x 12288 x 4096 as
+  // 256 whole 192 x 128 tiles + 32 tiles split 8 ways), measured 76.8 vs 81.3 us in the harness but 81.7 us inside bench.py
+  // (profiles/r02c_bench_kernel_stats.md) — no gain, so the 128 x 128 kernel keeps it and no model GEMM depends on a w4 exchange
+  if (split != 1 || p.M < 1024) return false;
   const float other = p8_est_us < old_kernels_estimate_us(p) ? p8_est_us : old_kernels_estimate_us(p);
-  // plans with a K-split exchange: only with a 10 % margin (their estimate is the optimistic one).  In the bench path that is the
-  // Llama qkv GEMM (576 x 12288 x 4096: 256 whole 192 x 128 tiles + 32 tiles split 8 ways = every workgroup 72 K units; 76.8 us
-  // against 81.3 us on the 128 x 128 kernel, profiles/r02_gemm_harness_llm_qkv.log)
-  return est < (split != 1 ? 0.90f : 0.97f) * other;
+  return est < 0.97f * other;
 }
 
 template <typename T>
