@@ -14,6 +14,7 @@
 //   * K tile rows are padded by 16 B and V^T rows by 8 B: conflict-free ds_read_b128 / ds_read_b64.
 //   * head_dim 88 (EVA-CLIP-g) is zero-padded to 96 in LDS/registers only; HBM traffic stays 88.
 // fp32 path ("verify" numerics): exact-fp32 vector kernel, one wave per query row.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -427,6 +428,218 @@ int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
   return STLLM_OK;
 }
 
+// ---- D = 128 prefill (Llama), round 2: windows staged by LDS-DMA, V read through the hardware transpose ----------------------------
+// Same work split as attn_resident_kernel<T, 128, 128, 4> (nw query tiles per workgroup, KS2 waves per query tile taking every
+// KS2-th 32-key tile, 128-key windows, LDS merge at the end), but the staging no longer passes through registers:
+//   * K and V rows of a window go global -> LDS with global_load_lds_dwordx4 (1 KiB = 4 rows per instruction, asynchronous) into
+//     ROW-MAJOR images; window w + 1 is requested right after the barrier that starts window w and lands during its MFMAs:
+//     ONE barrier per window, no ds_write, no V^T scatter (the old pass: 24 ds_write_b16 per thread and window);
+//   * bank conflicts are avoided on the SOURCE side: LDS slot (row, 16-byte chunk c) holds logical chunk c ^ (row & 15) for K
+//     (ds_read_b128 of 16 consecutive rows -> 16 different chunks) and c ^ ((row & 7) << 1) for V;
+//   * V^T fragments come from ds_read_b64_tr_b16: in a 16-lane group lane i fetches 8 bytes of row (key) base + i / 4 at column
+//     piece i % 4 and RECEIVES the four keys base .. base + 3 of column 4 (i / 4) + i % 4 = i — measured with tools/tr_probe.hip.
+// two transposing reads, at p and p + 2048 bytes (8 rows of a 256-byte-pitch image further down); see the layout note above
+__device__ __forceinline__ void lds_read_tr_pair(const char* p, unsigned long long& lo, unsigned long long& hi) {
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
+}
+
+template <typename T, int KS2>
+__global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
+  constexpr int DP = 128, KS = DP / 16, DB = DP / 32, W = 128;
+  constexpr int kImg = W * 256;                    // one K or V window image
+  constexpr int kBuf = 2 * kImg;                   // [K | V]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nwv = blockDim.x >> 6, nwaves = nwv / KS2;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all % nwaves, kpar = wave_all / nwaves;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * DP) * 2;
+  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * DP) * 2;
+  const int chunk = (int)gridDim.x - 1 - (int)blockIdx.x;   // heavy (late, causal) chunks first
+  const int qt = chunk * nwaves + wave;
+  const bool q_live = qt * 32 < p.Sq;
+  const int qrow = qt * 32 + li;
+  int kv_block_end = kvlen;
+  if (p.causal) kv_block_end = min(kv_block_end, (chunk + 1) * nwaves * 32);
+
+  i32x4 qf[KS];
+  {
+    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * DP) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      i32x4 z = {0, 0, 0, 0};
+      qf[ks] = qrow < p.Sq ? *reinterpret_cast<const i32x4*>(qp + (ks * 16 + lh * 8) * 2) : z;
+    }
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+  float m_run = kNeg, l_run = 0.0f;
+
+  // ---- window DMA: 64 pieces of 1 KiB (4 rows) per window: 32 of K, 32 of V; piece pc is issued by wave pc % nwv ---------------
+  auto issue_window = [&](int win0, int buf) {
+    for (int pc = wave_all; pc < 64; pc += nwv) {
+      const bool is_v = pc >= 32;
+      const int r4 = (pc & 31) * 4 + (lane >> 4);                 // window-relative row of this lane
+      const int pch = lane & 15;                                   // physical chunk
+      const int lc = is_v ? (pch ^ ((r4 & 7) << 1)) : (pch ^ (r4 & 15));
+      int row = win0 + r4;
+      row = row < p.Skv ? row : p.Skv - 1;                         // rows past the end: a valid row (masked keys / zero weights)
+      const char* src = (is_v ? vbase + (int64_t)row * p.v_rs * 2 : kbase + (int64_t)row * p.k_rs * 2) + lc * 16;
+      glds16(src, smem + buf * kBuf + (is_v ? kImg : 0) + (pc & 31) * 1024);
+    }
+  };
+  const int n_win = (kv_block_end + W - 1) / W;
+  if (n_win > 0) issue_window(0, 0);
+  for (int w = 0; w < n_win; ++w) {
+    const int win0 = w * W;
+    const int n_tiles = (min(W, kv_block_end - win0) + 31) >> 5;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of window w landed ...
+    __syncthreads();                                    // ... everybody's did, and everybody is done with window w - 1
+    if (w + 1 < n_win) issue_window(win0 + W, (w + 1) & 1);
+    if (q_live) {
+      const char* kimg = smem + (w & 1) * kBuf;
+      const char* vimg = kimg + kImg;
+      int t_end = n_tiles;
+      if (p.causal) t_end = min(n_tiles, qt + 1 - (win0 >> 5));
+      for (int t = 0; t < t_end; ++t) {
+        if (KS2 > 1 && (((win0 >> 5) + t) & (KS2 - 1)) != kpar) continue;
+        const int kv0 = win0 + t * 32;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        {
+          const int row = t * 32 + li;
+          const char* ka = kimg + row * 256;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const i32x4 kf = *reinterpret_cast<const i32x4*>(ka + (((ks * 2 + lh) ^ (row & 15)) << 4));
+            s = Elem<T>::mfma(kf, qf[ks], s);
+          }
+        }
+        const bool need_mask = (kv0 + 32 > kvlen) || (p.causal && kv0 + 31 > qt * 32);
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
+            s[r] = dead ? kNeg : s[r];
+          }
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float mc = m_new * p.scale_log2;
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -mc));
+          s[r] = pv;
+          rs += pv;
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (__any(m_new != m_run)) {
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          m_run = m_new;
+        }
+        l_run += rs;
+        // P V: lane (d = li, lh) needs the keys 16 a + 4 lh + {0..3, 8..11} of column d: two transposing reads of four keys each
+        const int i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, cb = (li >> 4) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          i32x4 pf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
+#pragma unroll
+          for (int i = 0; i < DB; ++i) {
+            unsigned long long lo, hi;
+            {
+              const int row = t * 32 + 16 * a + 4 * lh + jrow;       // (+ 8 for the second read: same row & 7)
+              const int pc8 = i * 8 + cb + piece;                    // 8-byte piece of the row: column 32 i + 16 (li >> 4) + 4 piece
+              // (all eight reads of a 16-key step in one asm block with a single wait measured SLOWER: 24.8 vs 22.7 us, and spilled)
+              lds_read_tr_pair(vimg + row * 256 + ((((pc8 >> 1) ^ ((row & 7) << 1))) << 4) + ((pc8 & 1) << 3), lo, hi);
+            }
+            const i32x4 vf = {(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
+            o[i] = Elem<T>::mfma(vf, pf, o[i]);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (KS2 > 1) {
+    float* mbuf = reinterpret_cast<float*>(smem);
+    for (int pp = 1; pp < KS2; ++pp) {
+      __syncthreads();
+      if (kpar == pp) {
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] = o[i][r];
+        mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane] = m_run;
+        mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane] = l_run;
+      }
+      __syncthreads();
+      if (kpar == 0) {
+        const float m1 = mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane];
+        const float l1 = mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.scale_log2), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.scale_log2);
+        l_run = l_run * a0 + l1 * a1;
+        m_run = m;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] * a1;
+      }
+    }
+    if (kpar != 0) return;
+  }
+  if (q_live && qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * DP;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * lh;
+        uint2 pk;
+        pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+        pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + d0) = pk;
+      }
+    }
+  }
+}
+
+static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 0 = the register-staged kernel for D = 128 prefill
+template <typename T, int KS2>
+int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
+  constexpr int lds = 2 * 2 * 128 * 256;   // two buffers of [K | V] windows
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int q_tiles = (p.Sq + 31) / 32;
+  int nw = nw_req < q_tiles ? nw_req : q_tiles;
+  dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw * KS2);
+  hipLaunchKernelGGL((attn_dma_kernel<T, KS2>), grid, block, lds, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention(dma)");
+  return STLLM_OK;
+}
+
 // ---- exact fp32 path: one wave per query row -----------------------------------------------------
 constexpr int kF32MaxKv = 2048;
 
@@ -496,7 +709,21 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
     return launch_mfma<T, 96, 3>(p, stream);
   }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
-  if (p.D == 128) return launch_resident<T, 128, 128, 4>(p, stream, 3);   // + four waves per query tile (every 4th key tile each)  // 128-key windows (2 workgroups/CU), 96 queries per workgroup
+  if (p.D == 128) {
+    if (g_attn_dma == -2) { const char* e = getenv("STLLM_ATTN_DMA"); g_attn_dma = e ? atoi(e) : 1; }
+    const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0 && (p.k_rs % 8) == 0 && (p.v_rs % 8) == 0 &&
+                    (p.k_bs % 8) == 0 && (p.v_bs % 8) == 0;
+    if (g_attn_dma != 0 && al && p.Skv >= 1) {   // LDS-DMA windows + transposing V reads (round 2)
+      // query tiles per workgroup x waves per query tile, measured at S = 576, 32 heads (us at B = 1 / B = 4): 12 x 1: 27.1 / 33.0,
+      // 6 x 2: 27.1 / 48.6, 4 x 2: 21.5 / 53.4, 3 x 4: 22.7 / 62.1 (register-staged kernel: 28.0 / 75.3) — the fewest key-split
+      // waves that still give >= 128 workgroups
+      const int q_tiles = (p.Sq + 31) / 32, bh = p.B * p.H;
+      if (bh * ((q_tiles + 11) / 12) >= 128) return launch_dma<T, 1>(p, stream, 12);
+      if (bh * ((q_tiles + 3) / 4) >= 128) return launch_dma<T, 2>(p, stream, 4);
+      return launch_dma<T, 4>(p, stream, 3);
+    }
+    return launch_resident<T, 128, 128, 4>(p, stream, 3);
+  }   // + four waves per query tile (every 4th key tile each)  // 128-key windows (2 workgroups/CU), 96 queries per workgroup
   stllm_set_error("stllm_attention: unsupported head_dim %d", p.D);
   return STLLM_ERR_UNSUPPORTED;
 }

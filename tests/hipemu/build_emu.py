@@ -38,6 +38,9 @@ def build(force=False):
         # inline ISA: a barrier that does not drain the LDS-DMA queue is a plain barrier here; bare waits vanish (copies are synchronous)
         text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\)', "__syncthreads()", text)
         text = re.sub(r'asm volatile\("s_waitcnt [a-z]+cnt\(\d+\)" ::: "memory"\)', "((void)0)", text)
+        # attention.hip: the pair of hardware transposing LDS reads -> the shim's emulation (hip_runtime.h: emu_ds_read_tr_b16)
+        text = re.sub(r'const unsigned a = \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) const char\*\)p;\s*asm volatile\("ds_read_b64_tr_b16[^;]*;',
+                      "lo = emu_ds_read_tr_b16(p); hi = emu_ds_read_tr_b16(p + 2048);", text)
         tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
         with open(tu, "w") as fh:
             fh.write(head + text)

@@ -251,7 +251,8 @@ def test_llama_training_graph_entirely_on_emulated_kernels():
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("shape", [dict(B=1, H=2, S=70, D=88, causal=False, lens=None),          # ViT-like (head_dim 88 padded to 96)
                                    dict(B=2, H=1, S=45, D=64, causal=False, lens=[45, 20]),       # Q-Former-like, key mask
-                                   dict(B=2, H=2, S=70, D=128, causal=True, lens=[70, 33])])      # Llama prefill, right padding
+                                   dict(B=2, H=2, S=70, D=128, causal=True, lens=[70, 33]),       # Llama prefill, right padding (LDS-DMA windows + transposing V reads)
+                                   dict(B=1, H=1, S=150, D=128, causal=True, lens=None)])         # ... two 128-key windows
 def test_emulated_forward_attention_matches_contract(dtype, shape):
     B, H, S, D = shape["B"], shape["H"], shape["S"], shape["D"]
     HD = H * D
