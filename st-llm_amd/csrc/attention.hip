@@ -438,10 +438,22 @@ int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
 //     (ds_read_b128 of 16 consecutive rows -> 16 different chunks) and c ^ ((row & 7) << 1) for V;
 //   * V^T fragments come from ds_read_b64_tr_b16: in a 16-lane group lane i fetches 8 bytes of row (key) base + i / 4 at column
 //     piece i % 4 and RECEIVES the four keys base .. base + 3 of column 4 (i / 4) + i % 4 = i — measured with tools/tr_probe.hip.
-// two transposing reads, at p and p + 2048 bytes (8 rows of a 256-byte-pitch image further down); see the layout note above
+// two transposing reads, at p and p + OFF bytes (8 rows of the image further down); see the layout note above
+template <int OFF = 2048>
 __device__ __forceinline__ void lds_read_tr_pair(const char* p, unsigned long long& lo, unsigned long long& hi) {
   const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(OFF) : "memory");
+}
+
+// three pairs (d-blocks 0, 1, 2 of an UNSWIZZLED row: 64 bytes apart) with a single wait
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr_3pairs(const char* p, unsigned long long& l0, unsigned long long& h0, unsigned long long& l1,
+                                                   unsigned long long& h1, unsigned long long& l2, unsigned long long& h2) {
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %6 offset:%7\n\t"
+               "ds_read_b64_tr_b16 %2, %6 offset:64\n\tds_read_b64_tr_b16 %3, %6 offset:%8\n\t"
+               "ds_read_b64_tr_b16 %4, %6 offset:128\n\tds_read_b64_tr_b16 %5, %6 offset:%9\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2) : "v"(a), "n"(OFF), "n"(OFF + 64), "n"(OFF + 128) : "memory");
 }
 
 template <typename T, int KS2>
@@ -623,7 +635,182 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
   }
 }
 
-static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 0 = the register-staged kernel for D = 128 prefill
+// ---- D = 88 (EVA ViT: 257 keys, padded to 96 dims x 288 keys): the same staging for the resident-K/V kernel -------------------------
+// One workgroup per (frame, head) and query chunk, one wave per 32-row query tile, the whole K and V of the head in LDS as
+// ROW-MAJOR images of 288 rows x 12 chunks of 16 bytes (chunk 11 = dims 88..95: a copy of chunk 10 — finite values that meet the
+// zero-padded Q / unstored output columns).  The 108 KiB arrive by LDS-DMA in three windows of 96 keys (4 one-KiB pieces per wave
+// and window at 9 waves); the waves start on window 0 while windows 1 and 2 are still in flight (counted vmcnt + one barrier per
+// window).  K slot (row, c) holds logical chunk c ^ ((row >> 2) & 3) (rows are 48 dwords apart: rows r and r + 4 share banks);
+// V needs no swizzle for the transposing reads (four consecutive rows = four disjoint 16-bank spans).
+template <typename T>
+__global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
+  constexpr int DP = 96, KS = DP / 16, DB = DP / 32, PITCH = 192, ROWS = 288;
+  constexpr int kImg = ROWS * PITCH;                 // 55 296 bytes = 54 pieces of 1 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int D = p.D;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
+  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
+  const int qt = blockIdx.x * nwaves + wave;
+  const bool q_live = qt * 32 < p.Sq;
+  const int qrow = qt * 32 + li;
+
+  // ---- staging: window w = rows 96 w .. 96 w + 95 of K (18 pieces) and of V (18 pieces); piece pc of a window by wave pc % nwaves
+  auto issue_window = [&](int w) {
+    for (int pc = wave; pc < 36; pc += nwaves) {
+      const bool is_v = pc >= 18;
+      const int idx = (w * 18 + (is_v ? pc - 18 : pc)) * 64 + lane;   // physical 16-byte slot of the image
+      const int r = idx / 12, pch = idx - r * 12;
+      int lc = is_v ? pch : (pch ^ ((r >> 2) & 3));
+      lc = lc < 11 ? lc : 10;
+      const int row = r < p.Skv ? r : p.Skv - 1;
+      const char* src = (is_v ? vbase + (int64_t)row * p.v_rs * 2 : kbase + (int64_t)row * p.k_rs * 2) + lc * 16;
+      glds16(src, smem + (is_v ? kImg : 0) + (idx - lane) * 16);
+    }
+  };
+  i32x4 qf[KS];
+  {
+    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + lh * 8;
+      i32x4 z = {0, 0, 0, 0};
+      qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
+    }
+  }
+  asm volatile("" ::: "memory");   // the Q loads are OLDER than the window DMAs: the first counted wait below covers them
+  const int n_win = (min(kvlen, ROWS) + 95) / 96;
+  for (int w = 0; w < n_win; ++w) issue_window(w);
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+  float m_run = kNeg, l_run = 0.0f;
+  const char* kimg = smem;
+  const char* vimg = smem + kImg;
+  const int i16 = lane & 15, jrow = i16 >> 2, piece = i16 & 3, cb = (li >> 4) * 4;
+  const int n_tiles = (min(kvlen, ROWS) + 31) >> 5;
+
+  for (int w = 0; w < n_win; ++w) {
+    // my pieces of windows 0..w landed (pieces are issued window by window, the same number per window for a given wave) ...
+    // (counted only in the ViT's shape — 9 waves: exactly 4 pieces per wave and window; any other wave count drains everything)
+    const int later = n_win - 1 - w;
+    if (nwaves == 9 && later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nwaves == 9 && later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // ... and everybody else's
+    if (!q_live) continue;
+    const int t_hi = min(n_tiles, 3 * (w + 1));
+    for (int t = 3 * w; t < t_hi; ++t) {
+      const int kv0 = t * 32;
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+      {
+        const int row = t * 32 + li;
+        const char* ka = kimg + row * PITCH;
+        const int sw = (row >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const i32x4 kf = *reinterpret_cast<const i32x4*>(ka + (((ks * 2 + lh) ^ sw) << 4));
+          s = Elem<T>::mfma(kf, qf[ks], s);
+        }
+      }
+      if (kv0 + 32 > kvlen) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          s[r] = kv >= kvlen ? kNeg : s[r];
+        }
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = m_new * p.scale_log2;
+      float rs = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -mc));
+        s[r] = pv;
+        rs += pv;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += rs;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        i32x4 pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
+        // the three pairs of transposing reads of this 16-key step in one block, ONE wait (registers to spare here: 120 of 170)
+        unsigned long long l0, h0, l1, h1, l2, h2;
+        {
+          const int row = t * 32 + 16 * a + 4 * lh + jrow;
+          lds_read_tr_3pairs<8 * PITCH>(vimg + row * PITCH + (cb + piece) * 8, l0, h0, l1, h1, l2, h2);
+        }
+        {
+          const i32x4 v0 = {(int)(unsigned)l0, (int)(unsigned)(l0 >> 32), (int)(unsigned)h0, (int)(unsigned)(h0 >> 32)};
+          const i32x4 v1 = {(int)(unsigned)l1, (int)(unsigned)(l1 >> 32), (int)(unsigned)h1, (int)(unsigned)(h1 >> 32)};
+          const i32x4 v2 = {(int)(unsigned)l2, (int)(unsigned)(l2 >> 32), (int)(unsigned)h2, (int)(unsigned)(h2 >> 32)};
+          o[0] = Elem<T>::mfma(v0, pf, o[0]);
+          o[1] = Elem<T>::mfma(v1, pf, o[1]);
+          o[2] = Elem<T>::mfma(v2, pf, o[2]);
+        }
+      }
+    }
+  }
+  if (q_live && qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * lh;
+        if (d0 < D) {
+          uint2 pk;
+          pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+          pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_dma88(const AttnParams& p, hipStream_t stream) {
+  constexpr int lds = 2 * 288 * 192;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma88_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int q_tiles = (p.Sq + 31) / 32;
+  const int nw = q_tiles < 12 ? q_tiles : 12;
+  dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw);
+  hipLaunchKernelGGL((attn_dma88_kernel<T>), grid, block, lds, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention(dma88)");
+  return STLLM_OK;
+}
+
+static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 1 (default) LDS-DMA kernel for the D = 128 prefill | 0 register-staged kernels
+                              // everywhere | 2 also the D = 88 (ViT) LDS-DMA variant — parity-tested, but it measures equal to the resident kernel (26.4 us)
 template <typename T, int KS2>
 int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
   constexpr int lds = 2 * 2 * 128 * 256;   // two buffers of [K | V] windows
@@ -705,7 +892,14 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
   //   ViT 257 -> 3 waves (96 rows, 3 blocks), Q-Former 32/44 -> 1-2 waves, Llama -> 3 waves (576 = 6*96)
   if (p.D == 88) {
     if (p.Sq <= 32) return launch_mfma<T, 96, 1>(p, stream);                       // BT-Adapter temporal attention
-    if (p.Skv <= 288 && !p.causal) return launch_resident<T, 96, 288>(p, stream);  // ViT: K/V of a head resident in LDS (a key split here re-stages K/V per query chunk: 26 -> 37 us)
+    if (p.Skv <= 288 && !p.causal) {
+      if (g_attn_dma == -2) { const char* e = getenv("STLLM_ATTN_DMA"); g_attn_dma = e ? atoi(e) : 1; }
+      const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0 && (p.k_rs % 8) == 0 && (p.v_rs % 8) == 0 &&
+                      (p.k_bs % 8) == 0 && (p.v_bs % 8) == 0;
+      if (g_attn_dma == 2 && al) return launch_dma88<T>(p, stream);   // LDS-DMA staging + transposing V reads: no faster here (the kernel is bound by
+                                                                      // the instruction stream of the SIMD that hosts 3 of the 9 waves), opt-in
+      return launch_resident<T, 96, 288>(p, stream);
+    }  // ViT: K/V of a head resident in LDS (a key split here re-stages K/V per query chunk: 26 -> 37 us)
     return launch_mfma<T, 96, 3>(p, stream);
   }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
@@ -953,6 +1147,7 @@ extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q
 }
 
 void stllm_attention_set_decode_single(int on) { g_decode_single = on; }
+void stllm_attention_set_dma(int v) { g_attn_dma = v; }
 
 extern "C" int64_t stllm_attention_decode_workspace_bytes(int B, int H, int Skv) {
   if (B <= 0 || H <= 0 || Skv <= 0) return -1;

@@ -1044,6 +1044,7 @@ extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_)
 extern "C" int64_t stllm_gemm_workspace_bytes(void) { return kSkFlagBytes + (int64_t)256 * 256 * 256 * 4; }  // = 512 slabs of 128x128 too
 
 void stllm_attention_set_decode_single(int on);   // attention.hip
+void stllm_attention_set_dma(int v);              // attention.hip
 
 extern "C" int stllm_set_option(const char* key, int value) {
   if (!key) return STLLM_ERR_BAD_SHAPE;
@@ -1053,6 +1054,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_w4")) { g_w4_mode = value; return STLLM_OK; }
   if (!strcmp(key, "gemv_mfma")) { stllm_gemv_set_mfma(value); return STLLM_OK; }
   if (!strcmp(key, "attn_decode_single")) { stllm_attention_set_decode_single(value); return STLLM_OK; }
+  if (!strcmp(key, "attn_dma")) { stllm_attention_set_dma(value); return STLLM_OK; }
   if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;

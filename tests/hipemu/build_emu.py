@@ -40,7 +40,10 @@ def build(force=False):
         text = re.sub(r'asm volatile\("s_waitcnt [a-z]+cnt\(\d+\)" ::: "memory"\)', "((void)0)", text)
         # attention.hip: the pair of hardware transposing LDS reads -> the shim's emulation (hip_runtime.h: emu_ds_read_tr_b16)
         text = re.sub(r'const unsigned a = \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) const char\*\)p;\s*asm volatile\("ds_read_b64_tr_b16[^;]*;',
-                      "lo = emu_ds_read_tr_b16(p); hi = emu_ds_read_tr_b16(p + 2048);", text)
+                      "lo = emu_ds_read_tr_b16(p); hi = emu_ds_read_tr_b16(p + OFF);", text, count=1)
+        text = re.sub(r'const unsigned a = \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) const char\*\)p;\s*asm volatile\("ds_read_b64_tr_b16[^;]*;',
+                      "l0 = emu_ds_read_tr_b16(p); h0 = emu_ds_read_tr_b16(p + OFF); l1 = emu_ds_read_tr_b16(p + 64); h1 = emu_ds_read_tr_b16(p + OFF + 64); "
+                      "l2 = emu_ds_read_tr_b16(p + 128); h2 = emu_ds_read_tr_b16(p + OFF + 128);", text, count=1)
         tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
         with open(tu, "w") as fh:
             fh.write(head + text)

@@ -695,12 +695,26 @@ ATTN_CASES = [  # name, B, H, Sq, Skv, D, causal, kv_len
     ("llama_causal", 2, 8, 200, 200, 128, True, None),
     ("llama_causal_pad", 2, 8, 131, 131, 128, True, [131, 97]),
     ("llama_short", 1, 4, 7, 7, 128, True, None),
+    ("llama_576", 1, 32, 576, 576, 128, True, None),              # the benchmarked prefill: 4 query tiles x 2 key-split waves per workgroup
+    ("llama_576_b2", 2, 32, 576, 576, 128, True, [576, 400]),     # >= 128 workgroups already with 12 query tiles x 1 wave
+    ("llama_noncausal", 2, 4, 300, 300, 128, False, [300, 170]),
 ]
 
 
+@pytest.mark.parametrize("dma", [1, 0, 2])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
-def test_attention(hip, dtype, case):
+def test_attention(hip, dtype, case, dma):
+    """every attention shape of the path against fp64; `attn_dma`: 1 = default (head_dim 128 on the LDS-DMA kernel with the hardware
+    transposing V reads), 0 = the register-staged kernels everywhere, 2 = also the head_dim 88 (ViT) LDS-DMA variant"""
+    hip.set_option("attn_dma", dma)
+    try:
+        _attention_case(hip, dtype, case)
+    finally:
+        hip.set_option("attn_dma", 1)
+
+
+def _attention_case(hip, dtype, case):
     _, B, H, Sq, Skv, D, causal, kv_len = case
     # q/k/v as column slices of one fused buffer, exactly how the model calls it
     C = 3 * H * D
