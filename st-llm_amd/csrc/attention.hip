@@ -33,6 +33,21 @@ struct AttnParams {
 
 constexpr float kNeg = -1.0e30f;
 
+// XCD-aware (batch, head, query-chunk) assignment.  The hardware deals workgroups round-robin over the 8 XCDs, each with its own
+// L2; with the natural order neighbouring heads of a frame (whose 176-byte K / V rows share cache lines at head_dim 88) and the
+// query chunks of one head (which re-read the same K / V) land on DIFFERENT XCDs, and every line is fetched 2-5 times from the
+// fabric — the ViT attention spent 38 % of its 26 us waiting for its first 36 KB (timeline: tools/attn_probe.hip).  The bijective
+// remap makes the linear ids that one XCD sees consecutive: all chunks of a head, then the next head of the same (frame, batch).
+__device__ __forceinline__ void attn_block_coords(int& chunk_x, int& h, int& b) {
+  const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int q = n >> 3, r = n & 7, xcd = lin & 7, k = lin >> 3;
+  const int id = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  chunk_x = id % gx;
+  h = (id / gx) % gy;
+  b = id / (gx * gy);
+}
+
 template <typename T, int DP, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_mfma_kernel(const AttnParams p) {
   constexpr int KS = DP / 16;          // k-steps of the S^T MFMA chain
@@ -220,13 +235,14 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
   const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, nwaves = (blockDim.x >> 6) / KS2;
   const int wave = wave_all % nwaves, kpar = wave_all / nwaves;   // query tile within the chunk, key-tile parity (KS2 = 2)
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx, b, h;
+  attn_block_coords(bx, h, b);
   const int D = p.D;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
   const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
-  // heavy (late, causal) chunks first: blockIdx.x counts down the query chunks
-  const int chunk = (int)gridDim.x - 1 - (int)blockIdx.x;
+  // heavy (late, causal) chunks first: the chunk index counts down
+  const int chunk = (int)gridDim.x - 1 - bx;
   const int qt = chunk * nwaves + wave;                 // this wave's query tile
   const bool q_live = qt * 32 < p.Sq;
   const int qrow = qt * 32 + li;
@@ -456,21 +472,28 @@ __device__ __forceinline__ void lds_read_tr_3pairs(const char* p, unsigned long 
                : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2) : "v"(a), "n"(OFF), "n"(OFF + 64), "n"(OFF + 128) : "memory");
 }
 
-template <typename T, int KS2>
+template <typename T, int KS2, int DP = 128>
 __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
-  constexpr int DP = 128, KS = DP / 16, DB = DP / 32, W = 128;
-  constexpr int kImg = W * 256;                    // one K or V window image
+  // DP = 128: Llama (256-byte rows, 128-key windows); DP = 96: head_dim 88 of the EVA ViT (rows of 11 chunks in a 12-chunk = 192-byte
+  // pitch, chunk 11 a copy of chunk 10 that meets zero-padded Q / unstored columns; 96-key windows, two workgroups per CU)
+  constexpr int KS = DP / 16, DB = DP / 32, CH = DP / 8, PITCH = CH * 16, W = DP == 128 ? 128 : 96;
+  constexpr int kPieces = W * CH / 64;              // 1-KiB DMA pieces per image (32 / 18)
+  constexpr int kImg = W * PITCH;                   // one K or V window image
   constexpr int kBuf = 2 * kImg;                   // [K | V]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, nwv = blockDim.x >> 6, nwaves = nwv / KS2;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave_all % nwaves, kpar = wave_all / nwaves;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx, b, h;
+  attn_block_coords(bx, h, b);
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
-  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * DP) * 2;
-  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * DP) * 2;
-  const int chunk = (int)gridDim.x - 1 - (int)blockIdx.x;   // heavy (late, causal) chunks first
+  const int D = p.D;
+  const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
+  const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
+  auto swk = [](int row) { return DP == 128 ? (row & 15) : ((row >> 2) & 3); };          // K: 16-byte chunk XOR (bank spread of ds_read_b128 over 16 rows)
+  auto swv = [](int row) { return DP == 128 ? ((row & 7) << 1) : 0; };                    // V: for the transposing reads (192-byte pitch needs none)
+  const int chunk = (int)gridDim.x - 1 - bx;   // heavy (late, causal) chunks first
   const int qt = chunk * nwaves + wave;
   const bool q_live = qt * 32 < p.Sq;
   const int qrow = qt * 32 + li;
@@ -479,11 +502,12 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
 
   i32x4 qf[KS];
   {
-    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * DP) * 2;
+    const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + lh * 8;
       i32x4 z = {0, 0, 0, 0};
-      qf[ks] = qrow < p.Sq ? *reinterpret_cast<const i32x4*>(qp + (ks * 16 + lh * 8) * 2) : z;
+      qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const i32x4*>(qp + d0 * 2) : z;
     }
   }
   f32x16 o[DB];
@@ -493,17 +517,19 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
   float m_run = kNeg, l_run = 0.0f;
 
-  // ---- window DMA: 64 pieces of 1 KiB (4 rows) per window: 32 of K, 32 of V; piece pc is issued by wave pc % nwv ---------------
+  // ---- window DMA: 2 x kPieces pieces of 1 KiB per window (K image, then V image); piece pc is issued by wave pc % nwv -------------
+  const int last_chunk = (D * 2 + 15) / 16 - 1;
   auto issue_window = [&](int win0, int buf) {
-    for (int pc = wave_all; pc < 64; pc += nwv) {
-      const bool is_v = pc >= 32;
-      const int r4 = (pc & 31) * 4 + (lane >> 4);                 // window-relative row of this lane
-      const int pch = lane & 15;                                   // physical chunk
-      const int lc = is_v ? (pch ^ ((r4 & 7) << 1)) : (pch ^ (r4 & 15));
+    for (int pc = wave_all; pc < 2 * kPieces; pc += nwv) {
+      const bool is_v = pc >= kPieces;
+      const int idx = (is_v ? pc - kPieces : pc) * 64 + lane;      // physical 16-byte slot of the image
+      const int r4 = idx / CH, pch = idx - r4 * CH;                // window-relative row, physical chunk
+      int lc = pch ^ (is_v ? swv(r4) : swk(r4));
+      lc = lc < last_chunk ? lc : last_chunk;
       int row = win0 + r4;
       row = row < p.Skv ? row : p.Skv - 1;                         // rows past the end: a valid row (masked keys / zero weights)
       const char* src = (is_v ? vbase + (int64_t)row * p.v_rs * 2 : kbase + (int64_t)row * p.k_rs * 2) + lc * 16;
-      glds16(src, smem + buf * kBuf + (is_v ? kImg : 0) + (pc & 31) * 1024);
+      glds16(src, smem + buf * kBuf + (is_v ? kImg : 0) + (idx - lane) * 16);
     }
   };
   const int n_win = (kv_block_end + W - 1) / W;
@@ -527,10 +553,10 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) s[r] = 0.0f;
         {
           const int row = t * 32 + li;
-          const char* ka = kimg + row * 256;
+          const char* ka = kimg + row * PITCH;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const i32x4 kf = *reinterpret_cast<const i32x4*>(ka + (((ks * 2 + lh) ^ (row & 15)) << 4));
+            const i32x4 kf = *reinterpret_cast<const i32x4*>(ka + (((ks * 2 + lh) ^ swk(row)) << 4));
             s = Elem<T>::mfma(kf, qf[ks], s);
           }
         }
@@ -581,7 +607,7 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
               const int row = t * 32 + 16 * a + 4 * lh + jrow;       // (+ 8 for the second read: same row & 7)
               const int pc8 = i * 8 + cb + piece;                    // 8-byte piece of the row: column 32 i + 16 (li >> 4) + 4 piece
               // (all eight reads of a 16-key step in one asm block with a single wait measured SLOWER: 24.8 vs 22.7 us, and spilled)
-              lds_read_tr_pair(vimg + row * 256 + ((((pc8 >> 1) ^ ((row & 7) << 1))) << 4) + ((pc8 & 1) << 3), lo, hi);
+              lds_read_tr_pair<8 * PITCH>(vimg + row * PITCH + (((pc8 >> 1) ^ swv(row)) << 4) + ((pc8 & 1) << 3), lo, hi);
             }
             const i32x4 vf = {(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
             o[i] = Elem<T>::mfma(vf, pf, o[i]);
@@ -620,16 +646,18 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
   }
   if (q_live && qrow < p.Sq) {
     const float inv = 1.0f / l_run;
-    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * DP;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
 #pragma unroll
     for (int i = 0; i < DB; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = i * 32 + 8 * g + 4 * lh;
-        uint2 pk;
-        pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
-        pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + d0) = pk;
+        if (d0 < D) {
+          uint2 pk;
+          pk.x = Elem<T>::pack2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+          pk.y = Elem<T>::pack2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(op + d0) = pk;
+        }
       }
     }
   }
@@ -650,12 +678,13 @@ __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx, b, h;
+  attn_block_coords(bx, h, b);
   const int D = p.D;
   const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
   const char* kbase = p.k + ((int64_t)b * p.k_bs + (int64_t)h * D) * 2;
   const char* vbase = p.v + ((int64_t)b * p.v_bs + (int64_t)h * D) * 2;
-  const int qt = blockIdx.x * nwaves + wave;
+  const int qt = bx * nwaves + wave;
   const bool q_live = qt * 32 < p.Sq;
   const int qrow = qt * 32 + li;
 
@@ -809,20 +838,25 @@ int launch_dma88(const AttnParams& p, hipStream_t stream) {
   return STLLM_OK;
 }
 
-static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 1 (default) LDS-DMA kernel for the D = 128 prefill | 0 register-staged kernels
-                              // everywhere | 2 also the D = 88 (ViT) LDS-DMA variant — parity-tested, but it measures equal to the resident kernel (26.4 us)
-template <typename T, int KS2>
+static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 1 (default) LDS-DMA kernels for head_dim 128 (Llama prefill) and 88 (ViT) |
+                              // 0 register-staged kernels everywhere
+template <typename T, int KS2, int DP = 128>
 int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
-  constexpr int lds = 2 * 2 * 128 * 256;   // two buffers of [K | V] windows
+  constexpr int W = DP == 128 ? 128 : 96;
+  constexpr int lds = 2 * 2 * W * (DP * 2);   // two buffers of [K | V] windows (128 KiB at 128 dims, 72 KiB at 96: two workgroups per CU)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int q_tiles = (p.Sq + 31) / 32;
   int nw = nw_req < q_tiles ? nw_req : q_tiles;
+  if (KS2 > 1 && nw * (DP / 32 * 16 + 2) * 256 > lds) {
+    stllm_set_error("stllm_attention(dma): key-split merge buffer does not fit (nw=%d)", nw);
+    return STLLM_ERR_UNSUPPORTED;
+  }
   dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw * KS2);
-  hipLaunchKernelGGL((attn_dma_kernel<T, KS2>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((attn_dma_kernel<T, KS2, DP>), grid, block, lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_attention(dma)");
   return STLLM_OK;
 }
@@ -896,8 +930,9 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
       if (g_attn_dma == -2) { const char* e = getenv("STLLM_ATTN_DMA"); g_attn_dma = e ? atoi(e) : 1; }
       const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0 && (p.k_rs % 8) == 0 && (p.v_rs % 8) == 0 &&
                       (p.k_bs % 8) == 0 && (p.v_bs % 8) == 0;
-      if (g_attn_dma == 2 && al) return launch_dma88<T>(p, stream);   // LDS-DMA staging + transposing V reads: no faster here (the kernel is bound by
-                                                                      // the instruction stream of the SIMD that hosts 3 of the 9 waves), opt-in
+      // LDS-DMA staging in three 96-key windows + transposing V reads: 23.2 vs 24.1 us for the register-staged resident kernel (both
+      // after the XCD-aware block mapping; 26.3 vs 27.1 before it)
+      if (g_attn_dma != 0 && al) return launch_dma88<T>(p, stream);
       return launch_resident<T, 96, 288>(p, stream);
     }  // ViT: K/V of a head resident in LDS (a key split here re-stages K/V per query chunk: 26 -> 37 us)
     return launch_mfma<T, 96, 3>(p, stream);

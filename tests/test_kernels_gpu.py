@@ -701,12 +701,12 @@ ATTN_CASES = [  # name, B, H, Sq, Skv, D, causal, kv_len
 ]
 
 
-@pytest.mark.parametrize("dma", [1, 0, 2])
+@pytest.mark.parametrize("dma", [1, 0])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
 def test_attention(hip, dtype, case, dma):
     """every attention shape of the path against fp64; `attn_dma`: 1 = default (head_dim 128 on the LDS-DMA kernel with the hardware
-    transposing V reads), 0 = the register-staged kernels everywhere, 2 = also the head_dim 88 (ViT) LDS-DMA variant"""
+    transposing V reads, head_dim 88 likewise), 0 = the register-staged kernels everywhere"""
     hip.set_option("attn_dma", dma)
     try:
         _attention_case(hip, dtype, case)
