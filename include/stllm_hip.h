@@ -124,7 +124,11 @@ int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
  * 44 (256 x 256).  heavy bit 3 (| 8): the epilogue is STORE / RESID, so a last tile row of <= 32 rows is computed outside the tile
  * grid ("thin tail": ViT fc1's 4112 rows = 16 tile rows + 16 rows) and does not count as tiles. */
 int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
-/* tuning / test hooks:
+/* tuning / test hooks.  Option state is PER THREAD (thread-local, like the error string): the first stllm_* call of a host thread reads the
+ * STLLM_GEMM_SK / _DEBUG / _GEMV / _P8 / _W4, STLLM_GEMV_MFMA, STLLM_ATTN_DMA, STLLM_ATTN_BWD_VALU, STLLM_NORM_FAST environment variables once,
+ * stllm_set_option() changes the calling thread's copy only — two host threads driving different streams / devices never race on it.
+ * Per-device launch state (dynamic-LDS opt-in, occupancy answers) is kept per device ordinal.
+ * The fused-RMSNorm operand (a_norm_*) exists in the GEMV kernels only: "gemm_gemv" = 0 and forced tile kernels do not apply to it.
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
@@ -138,7 +142,9 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *                  0 register-staged kernels
  *   "attn_decode_single" = 1 (default) one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
- *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp) */
+ *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp)
+ *   "attn_bwd_valu" = 0 (default) MFMA attention backward for 16-bit operands | 1 the VALU twins
+ *   "norm_fast"  = 1 (default) | 0: round-1 LayerNorm / RMSNorm kernels */
 int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);
 

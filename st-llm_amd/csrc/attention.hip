@@ -424,11 +424,13 @@ template <typename T, int DP, int SKV_MAX, int KS2 = 1>
 int launch_resident(const AttnParams& p, hipStream_t stream, int nw_req = 0) {
   constexpr int lds = SKV_MAX * (DP * 2 + 16) + DP * (SKV_MAX * 2 + 8);
 
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_resident_kernel<T, DP, SKV_MAX, KS2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   const int q_tiles = (p.Sq + 31) / 32;
   int nw = nw_req > 0 ? nw_req : q_tiles;
@@ -825,10 +827,12 @@ __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
 template <typename T>
 int launch_dma88(const AttnParams& p, hipStream_t stream) {
   constexpr int lds = 2 * 288 * 192;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma88_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   const int q_tiles = (p.Sq + 31) / 32;
   const int nw = q_tiles < 12 ? q_tiles : 12;
@@ -838,16 +842,18 @@ int launch_dma88(const AttnParams& p, hipStream_t stream) {
   return STLLM_OK;
 }
 
-static int g_attn_dma = -2;   // env STLLM_ATTN_DMA / option "attn_dma": 1 (default) LDS-DMA kernels for head_dim 128 (Llama prefill) and 88 (ViT) |
+// env STLLM_ATTN_DMA / option "attn_dma" (stllm_options().attn_dma): 1 (default) LDS-DMA kernels for head_dim 128 (Llama prefill) and 88 (ViT) |
                               // 0 register-staged kernels everywhere
 template <typename T, int KS2, int DP = 128>
 int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
   constexpr int W = DP == 128 ? 128 : 96;
   constexpr int lds = 2 * 2 * W * (DP * 2);   // two buffers of [K | V] windows (128 KiB at 128 dims, 72 KiB at 96: two workgroups per CU)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   const int q_tiles = (p.Sq + 31) / 32;
   int nw = nw_req < q_tiles ? nw_req : q_tiles;
@@ -927,7 +933,7 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
   if (p.D == 88) {
     if (p.Sq <= 32) return launch_mfma<T, 96, 1>(p, stream);                       // BT-Adapter temporal attention
     if (p.Skv <= 288 && !p.causal) {
-      if (g_attn_dma == -2) { const char* e = getenv("STLLM_ATTN_DMA"); g_attn_dma = e ? atoi(e) : 1; }
+      const int g_attn_dma = stllm_options().attn_dma;
       const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0 && (p.k_rs % 8) == 0 && (p.v_rs % 8) == 0 &&
                       (p.k_bs % 8) == 0 && (p.v_bs % 8) == 0;
       // LDS-DMA staging in three 96-key windows + transposing V reads: 23.2 vs 24.1 us for the register-staged resident kernel (both
@@ -939,7 +945,7 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
   }
   if (p.D == 64) return p.Sq <= 32 ? launch_mfma<T, 64, 1>(p, stream) : launch_mfma<T, 64, 2>(p, stream);
   if (p.D == 128) {
-    if (g_attn_dma == -2) { const char* e = getenv("STLLM_ATTN_DMA"); g_attn_dma = e ? atoi(e) : 1; }
+    const int g_attn_dma = stllm_options().attn_dma;
     const bool al = ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15) == 0 && (p.k_rs % 8) == 0 && (p.v_rs % 8) == 0 &&
                     (p.k_bs % 8) == 0 && (p.v_bs % 8) == 0;
     if (g_attn_dma != 0 && al && p.Skv >= 1) {   // LDS-DMA windows + transposing V reads (round 2)
@@ -1140,7 +1146,7 @@ __global__ __launch_bounds__(64 * kDecWaves) void attn_decode_single_kernel(cons
   }
 }
 
-static int g_decode_single = 1;   // stllm_set_option("attn_decode_single", 0): always the split-KV pair (tests compare both)
+// stllm_set_option("attn_decode_single", 0): always the split-KV pair (tests compare both)
 static int decode_splits(int Skv) {
   int n = (Skv + 47) / 48;   // ~48 keys (12 per wave) per workgroup
   return n < 1 ? 1 : (n > 64 ? 64 : n);
@@ -1181,8 +1187,6 @@ extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q
   return STLLM_ERR_BAD_DTYPE;
 }
 
-void stllm_attention_set_decode_single(int on) { g_decode_single = on; }
-void stllm_attention_set_dma(int v) { g_attn_dma = v; }
 
 extern "C" int64_t stllm_attention_decode_workspace_bytes(int B, int H, int Skv) {
   if (B <= 0 || H <= 0 || Skv <= 0) return -1;
@@ -1211,7 +1215,7 @@ extern "C" int stllm_attention_decode(int dtype, const void* q, int64_t q_bs, co
   p.B = B; p.H = H; p.Sq = 1; p.Skv = Skv; p.D = D;
   p.scale = scale; p.scale_log2 = scale * 1.44269504088896340736f;
   if ((Skv <= kDecSingleMax || B * H >= 256) && aligned16(q) && aligned16(k) && aligned16(v) && q_bs % 8 == 0 && k_bs % 8 == 0 &&
-      k_rs % 8 == 0 && v_bs % 8 == 0 && v_rs % 8 == 0 && g_decode_single) {
+      k_rs % 8 == 0 && v_bs % 8 == 0 && v_rs % 8 == 0 && stllm_options().attn_decode_single) {
     if (dtype == STLLM_BF16) hipLaunchKernelGGL(attn_decode_single_kernel<bf16_t>, dim3(H, B), dim3(64 * kDecWaves), 0, stream, p);
     else hipLaunchKernelGGL(attn_decode_single_kernel<f16_t>, dim3(H, B), dim3(64 * kDecWaves), 0, stream, p);
     STLLM_CHECK_LAUNCH("stllm_attention_decode(single)");

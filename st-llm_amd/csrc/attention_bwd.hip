@@ -542,14 +542,16 @@ template <typename T, int DP>
 int launch_bwd(Ptr q, Ptr k, Ptr v, Ptr o, Ptr dO, MPtr dq, MPtr dk, MPtr dv, float* ws, int B, const BwdDims& p, hipStream_t st) {
   constexpr int LD = DP + 4;
   constexpr int lds_stats = 2 * kT * LD * 4, lds_dq = (4 * kT * LD + kT * 33) * 4, lds_dkv = (4 * kT * LD + 2 * kT * 33) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv) != hipSuccess) {
       stllm_set_error("stllm_attention_bwd: cannot raise the dynamic LDS limit");
       return STLLM_ERR_HIP;
     }
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   const dim3 gq((p.Sq + kT - 1) / kT, p.H, B), gk((p.Skv + kT - 1) / kT, p.H, B), block(256);
   hipLaunchKernelGGL((attn_bwd_stats_kernel<T, DP>), gq, block, lds_stats, st, q, k, o, dO, ws, p);
@@ -589,8 +591,7 @@ extern "C" int stllm_attention_bwd(int dtype, const void* q, int64_t q_bs, int64
   float* ws = reinterpret_cast<float*>(workspace);
   const BwdDims dims{H, Sq, Skv, D, scale, causal, kv_len};
   int rc;
-  const char* force = getenv("STLLM_ATTN_BWD_VALU");
-  const bool mfma = !(force && force[0] == '1');      // 16-bit operands: MFMA kernels; fp32 always runs the fp32-FMA kernels
+  const bool mfma = stllm_options().attn_bwd_valu != 1;      // 16-bit operands: MFMA kernels; fp32 always runs the fp32-FMA kernels
   switch (dtype) {
     case STLLM_BF16: rc = mfma ? launch_bwd_mfma<bf16_t>(Q, K, V, O, DO, DQ, DK, DV, ws, B, H, Sq, Skv, D, scale, causal, kv_len, s)
                                : launch_bwd_dp<bf16_t>(D, Q, K, V, O, DO, DQ, DK, DV, ws, B, dims, s); break;

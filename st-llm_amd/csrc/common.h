@@ -33,6 +33,29 @@ void stllm_set_last_kernel(const char* name);  // static-lifetime string: symbol
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------------------------
+// host: dispatch options — per THREAD (include/stllm_hip.h: no process-global state besides thread-local data).  The first use in
+// a thread reads the STLLM_* environment variables ONCE, all of them, before any dispatch decision; stllm_set_option() writes the
+// calling thread's copy (a test / experiment hook: two host threads with different options do not race).
+// ---------------------------------------------------------------------------------------------
+#include "options.h"
+
+// Function attributes (dynamic LDS opt-in) and occupancy answers are PER DEVICE: one bit per device ordinal and call site, so a
+// process that drives several GPUs sets them on each (a process-wide `static bool` left device 1 without the opt-in).
+struct StllmPerDevice {
+  unsigned long long seen = 0;
+  int value[64] = {0};
+  // current device ordinal; *first = true when this call site has not run on that device yet
+  int enter(bool* first) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    *first = !((__atomic_load_n(&seen, __ATOMIC_ACQUIRE) >> dev) & 1ull);
+    return dev;
+  }
+  void done(int dev) { __atomic_fetch_or(&seen, 1ull << dev, __ATOMIC_RELEASE); }
+};
+
+// ---------------------------------------------------------------------------------------------
 // device: vector types
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -2,11 +2,16 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <thread>
 #include <vector>
 
 #include "../../include/stllm_hip.h"
+#include "options.h"
+
+void stllm_set_error(const char* fmt, ...);
 
 static thread_local char g_err[512] = "";
 
@@ -19,6 +24,47 @@ void stllm_set_error(const char* fmt, ...) {
 
 extern "C" const char* stllm_last_error(void) { return g_err; }
 extern "C" int stllm_abi_version(void) { return 2; }   // 2: stllm_gemm_args gained the trailing a_norm_* fields (round 2)
+
+// ---- per-thread dispatch options (common.h) ----
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+StllmOptions& stllm_options() {
+  static thread_local StllmOptions o;
+  static thread_local bool init = false;
+  if (!init) {   // every variable in ONE place, before the first dispatch decision of this thread
+    o.gemm_sk = env_int("STLLM_GEMM_SK", -1);
+    o.gemm_debug = env_int("STLLM_GEMM_DEBUG", 0);
+    o.gemm_gemv = env_int("STLLM_GEMM_GEMV", -1);
+    o.gemm_p8 = env_int("STLLM_GEMM_P8", -1);
+    o.gemm_w4 = env_int("STLLM_GEMM_W4", -1);
+    o.gemv_mfma = env_int("STLLM_GEMV_MFMA", -1);
+    o.attn_decode_single = 1;
+    o.attn_dma = env_int("STLLM_ATTN_DMA", 1);
+    o.attn_bwd_valu = env_int("STLLM_ATTN_BWD_VALU", 0);
+    o.norm_fast = env_int("STLLM_NORM_FAST", 1);
+    init = true;
+  }
+  return o;
+}
+
+extern "C" int stllm_set_option(const char* key, int value) {
+  if (!key) return STLLM_ERR_BAD_SHAPE;
+  StllmOptions& o = stllm_options();
+  if (!strcmp(key, "gemm_sk")) { o.gemm_sk = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_debug")) { o.gemm_debug = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_p8")) { o.gemm_p8 = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_w4")) { o.gemm_w4 = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_gemv")) { o.gemm_gemv = value; return STLLM_OK; }
+  if (!strcmp(key, "gemv_mfma")) { o.gemv_mfma = value; return STLLM_OK; }
+  if (!strcmp(key, "attn_decode_single")) { o.attn_decode_single = value; return STLLM_OK; }
+  if (!strcmp(key, "attn_dma")) { o.attn_dma = value; return STLLM_OK; }
+  if (!strcmp(key, "attn_bwd_valu")) { o.attn_bwd_valu = value; return STLLM_OK; }
+  if (!strcmp(key, "norm_fast")) { o.norm_fast = value; return STLLM_OK; }
+  stllm_set_error("stllm_set_option: unknown key %s", key);
+  return STLLM_ERR_UNSUPPORTED;
+}
 
 static thread_local const char* g_last_kernel = "";
 void stllm_set_last_kernel(const char* name) { g_last_kernel = name; }

@@ -68,7 +68,7 @@ __device__ __forceinline__ i32x4 patch_chunk(const float* __restrict__ frames, i
   return r;
 }
 
-static int g_debug_early() { static int d = -1; if (d < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); d = e ? atoi(e) : 0; } return d; }
+static int g_debug_early() { return stllm_options().gemm_debug; }
 
 template <typename T, int BM, int BN, int EPI, int ACT, bool OF32>
 __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kernel(const GemmParams p) {
@@ -394,16 +394,21 @@ int launch(const GemmParams& p0, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / BN;
   const int lds = Tile<BM, BN>::kLdsBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, BM, BN, EPI, ACT, OF32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   // persistent grid: every workgroup is resident (LDS-limited workgroups per CU x 256 CUs)
   const int ntiles = p.tiles_m * p.tiles_n;
-  static int max_wg = 0;
-  if (max_wg == 0) {
+  static StllmPerDevice occ_dev;   // resident workgroups per device ordinal
+  bool occ_first;
+  const int occ_d = occ_dev.enter(&occ_first);
+  if (occ_first) {
+    int max_wg;
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     (void)hipGetDevice(&dev);
@@ -412,7 +417,10 @@ int launch(const GemmParams& p0, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     max_wg = per_cu * prop.multiProcessorCount;
     if (g_debug_early() & 8) fprintf(stderr, "[stllm] gemm<%d,%d> occupancy %d WG/CU x %d CUs\n", BM, BN, per_cu, prop.multiProcessorCount);
+    occ_dev.value[occ_d] = max_wg;
+    occ_dev.done(occ_d);
   }
+  const int max_wg = occ_dev.value[occ_d];
   const int grid = ntiles < max_wg ? ntiles : max_wg;
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI, ACT, OF32>), dim3(grid), dim3(kThreads), lds, stream, p);
   STLLM_CHECK_LAUNCH("stllm_gemm");
@@ -772,17 +780,22 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const int lds = SkTile<BM, BN>::kLdsBytes;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
+  bool attr_first;
+  const int attr_d = attr_dev.enter(&attr_first);
+  if (attr_first) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+    attr_dev.done(attr_d);
   }
   const int64_t total = (int64_t)p.tiles_m * p.tiles_n * (p.K / (kRowBytes / Elem<T>::kBytes));
   // every workgroup must be RESIDENT (finalisers wait for contributors): size the grid from the occupancy query, never
   // from an assumption (MI355X_MICROARCH "Residency and cooperative launch"); one fewer per CU keeps a margin
-  static int max_wg = 0;
-  if (max_wg == 0) {
+  static StllmPerDevice occ_dev;   // resident workgroups per device ordinal
+  bool occ_first;
+  const int occ_d = occ_dev.enter(&occ_first);
+  if (occ_first) {
+    int max_wg;
     int per_cu = 0, dev = 0;
     hipDeviceProp_t prop;
     (void)hipGetDevice(&dev);
@@ -793,7 +806,10 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     max_wg = per_cu * prop.multiProcessorCount;
     if (g_debug_early() & 8) fprintf(stderr, "[stllm] gemm_sk<%d,%d> occupancy %d WG/CU x %d CUs\n", BM, BN, per_cu, prop.multiProcessorCount);
+    occ_dev.value[occ_d] = max_wg;
+    occ_dev.done(occ_d);
   }
+  const int max_wg = occ_dev.value[occ_d];
   const int grid = total < max_wg ? (int)total : max_wg;
   p.epoch = stllm_sk_next_epoch();
   hipLaunchKernelGGL((gemm_sk_kernel<T, BM, BN, EPI, ACT, OF32>), dim3(grid), dim3(SkTile<BM, BN>::NT), lds, stream, p);
@@ -813,14 +829,8 @@ int launch_sk(const GemmParams& p0, hipStream_t stream) {
 }
 
 // stream-K eligibility + tile: returns 0 (off) | 1 = 128x128 | 2 = 128x256 | 3 = 256x256
-static int g_sk_mode = -2;  // env STLLM_GEMM_SK / stllm_set_option("gemm_sk"): -1 auto, 0 off, 1/2/3 force a tile
-static int g_debug = -1;    // env STLLM_GEMM_DEBUG / stllm_set_option("gemm_debug")
-static int g_gemv_mode = -2;  // stllm_set_option("gemm_gemv")
-static int g_p8_mode = -2;  // env STLLM_GEMM_P8 / stllm_set_option("gemm_p8"): -1 auto, 0 off, 1 phased kernel (3 / 4: force 192 / 256 rows)
-static int g_w4_mode = -2;  // env STLLM_GEMM_W4 / stllm_set_option("gemm_w4"): -1 auto, 0 off, 1 one-wave-per-SIMD kernel (34 / 44: force the tile)
 static int sk_choice(const GemmParams& p, int eb) {
-  if (g_sk_mode == -2) { const char* e = getenv("STLLM_GEMM_SK"); g_sk_mode = e ? atoi(e) : -1; }
-  const int mode = g_sk_mode;
+  const int mode = stllm_options().gemm_sk;
   if (mode == 0 || p.ws == nullptr) return 0;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)kSkMaxSlabWG * 128 * 128 * 4) return 0;
   if (mode >= 1 && mode <= 3) return mode;
@@ -871,7 +881,7 @@ int dispatch_store(const GemmParams& p, hipStream_t stream) {
 // auto: when its cost model beats the estimate for the 128x128 kernels by a margin (both calibrated on MI355X, see
 // profiles/r01_gemm_p8.md; a wrong guess near the margin costs a few percent either way).
 static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
-  if (g_p8_mode == -2) { const char* e = getenv("STLLM_GEMM_P8"); g_p8_mode = e ? atoi(e) : -1; }
+  const int g_p8_mode = stllm_options().gemm_p8, g_sk_mode = stllm_options().gemm_sk;
   if (g_p8_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
   const float est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, miw);
@@ -900,7 +910,7 @@ static float old_kernels_estimate_us(const GemmParams& p) {
 // estimate beats both other kernel families — in the bench path that is the ViT's N = 1408 GEMMs (proj, fc2) as ONE round
 // of 242 tiles of 192 x 128.
 static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_us) {
-  if (g_w4_mode == -2) { const char* e = getenv("STLLM_GEMM_W4"); g_w4_mode = e ? atoi(e) : -1; }
+  const int g_w4_mode = stllm_options().gemm_w4, g_p8_mode = stllm_options().gemm_p8, g_sk_mode = stllm_options().gemm_sk;
   if (g_w4_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
   int split = 1;
@@ -923,9 +933,8 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
 template <typename T>
 int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stream) {
   if constexpr (!Elem<T>::kIsF32) {
-    static int gemv_mode = -2;   // env STLLM_GEMM_GEMV / stllm_set_option("gemm_gemv"): -1 / 2 = GEMV up to M = 8 (the 5 beams of demo.py), 1 = up to M = 4, 0 = off
-    if (gemv_mode == -2) { const char* e = getenv("STLLM_GEMM_GEMV"); gemv_mode = e ? atoi(e) : -1; }
-    if (g_gemv_mode != -2) gemv_mode = g_gemv_mode;
+    const StllmOptions& o_ = stllm_options();   // this thread's options: env parsed once, before any decision below
+    const int gemv_mode = o_.gemm_gemv, g_sk_mode = o_.gemm_sk, g_p8_mode = o_.gemm_p8, g_w4_mode = o_.gemm_w4;
     const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
     if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
@@ -1015,8 +1024,7 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   p.aux0 = a->aux0; p.aux1 = a->aux1; p.frames = a->frames;
   p.rope_seq = a->rope_seq; p.rope_cols = a->rope_cols;
   p.M = a->M; p.N = a->N; p.K = K; p.act = a->act; p.out_is_f32 = a->out_is_f32;
-  if (g_debug < 0) { const char* e = getenv("STLLM_GEMM_DEBUG"); g_debug = e ? atoi(e) : 0; }
-  p.debug = g_debug;
+  p.debug = stllm_options().gemm_debug;
   p.ws = reinterpret_cast<char*>(a->workspace); p.ws_bytes = a->workspace_bytes;
   p.nx = a->a_norm_x; p.nx_ld = a->a_norm_ldx; p.ngamma = a->a_norm_gamma; p.neps = a->a_norm_eps;
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
@@ -1043,19 +1051,3 @@ extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_)
 
 extern "C" int64_t stllm_gemm_workspace_bytes(void) { return kSkFlagBytes + (int64_t)256 * 256 * 256 * 4; }  // = 512 slabs of 128x128 too
 
-void stllm_attention_set_decode_single(int on);   // attention.hip
-void stllm_attention_set_dma(int v);              // attention.hip
-
-extern "C" int stllm_set_option(const char* key, int value) {
-  if (!key) return STLLM_ERR_BAD_SHAPE;
-  if (!strcmp(key, "gemm_sk")) { g_sk_mode = value; return STLLM_OK; }
-  if (!strcmp(key, "gemm_debug")) { g_debug = value; return STLLM_OK; }
-  if (!strcmp(key, "gemm_p8")) { g_p8_mode = value; return STLLM_OK; }
-  if (!strcmp(key, "gemm_w4")) { g_w4_mode = value; return STLLM_OK; }
-  if (!strcmp(key, "gemv_mfma")) { stllm_gemv_set_mfma(value); return STLLM_OK; }
-  if (!strcmp(key, "attn_decode_single")) { stllm_attention_set_decode_single(value); return STLLM_OK; }
-  if (!strcmp(key, "attn_dma")) { stllm_attention_set_dma(value); return STLLM_OK; }
-  if (!strcmp(key, "gemm_gemv")) { g_gemv_mode = value; return STLLM_OK; }
-  stllm_set_error("stllm_set_option: unknown key %s", key);
-  return STLLM_ERR_UNSUPPORTED;
-}

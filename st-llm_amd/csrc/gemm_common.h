@@ -62,7 +62,6 @@ int stllm_gemm_p8_launch_bf16(int epilogue, int miw, const sg::GemmParams& p, hi
 int stllm_gemm_p8_launch_f16(int epilogue, int miw, const sg::GemmParams& p, hipStream_t stream);
 // skinny GEMM of the decode regime (gemv.hip): M <= 4, 16-bit dtypes, every epilogue except PATCH
 int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream);
-void stllm_gemv_set_mfma(int v);   // option "gemv_mfma": -1 matrix-core kernel from M = 3, 0 never, 1 from M = 1
 float stllm_gemm_p8_estimate_us(int M, int N, int K, int heavy_epilogue, int* miw);   // cost model of the schedule; picks MIW (4: 256 rows, 3: 192 rows)
 // one-wave-per-SIMD kernel (gemm_w4.inc): 4 waves x up to 256 accumulator registers, tile shape 34 (192 x 256) or 44 (256 x 256);
 // same workspace, same epilogues and return codes as the phased kernel

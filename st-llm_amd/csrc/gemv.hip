@@ -365,10 +365,13 @@ template <typename T, int EPI, int ACT, bool OF32, int MR>
 int launch_gemv(const GemmParams& p, hipStream_t stream) {
   auto kern = gemv_kernel<T, EPI, ACT, OF32, MR>;
   const int lds = MR * p.K * 2;
-  static int lds_set = 0;
-  if (lds > lds_set) {
+  static StllmPerDevice lds_dev;   // largest dynamic-LDS size opted into, per device ordinal
+  bool lds_first;
+  const int lds_d = lds_dev.enter(&lds_first);
+  if (lds_first || lds > lds_dev.value[lds_d]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return STLLM_ERR_UNSUPPORTED;
-    lds_set = lds;
+    lds_dev.value[lds_d] = lds;
+    lds_dev.done(lds_d);
   }
   const int pairs = p.N / 2;
   hipLaunchKernelGGL(kern, dim3((pairs + 3) / 4), dim3(256), lds, stream, p);
@@ -417,12 +420,10 @@ int dispatch_gemv(int epilogue, const GemmParams& p, hipStream_t stream) {
 // kernel (K % 64 == 0; A is read straight from global memory, no LDS limit); otherwise, for M <= 8, the VALU kernel,
 // whose staged rows (1, 2, 4, 6 or 8 x K x 2 bytes) must fit the LDS.  Returns STLLM_ERR_UNSUPPORTED when neither applies (the caller
 // falls back to the tile kernels).
-static int g_gemv_mfma = -2;
-void stllm_gemv_set_mfma(int v) { g_gemv_mfma = v; }
 int stllm_gemv_launch(int dtype, int epilogue, const sg::GemmParams& p, hipStream_t stream) {
   if (p.M < 1 || p.M > 16) return STLLM_ERR_UNSUPPORTED;
   if (p.N % 64 || p.K % 8 || (p.ldw_b % 16) || (!p.nx && (p.lda_b % 16))) return STLLM_ERR_UNSUPPORTED;
-  if (g_gemv_mfma == -2) { const char* e = getenv("STLLM_GEMV_MFMA"); g_gemv_mfma = e ? atoi(e) : -1; }
+  const int g_gemv_mfma = stllm_options().gemv_mfma;
   const int from = g_gemv_mfma == 0 ? 17 : g_gemv_mfma >= 1 ? g_gemv_mfma : 3;   // n >= 1: from M = n
   if (!p.nx && p.M >= from && p.K % 64 == 0) {
     if (dtype == STLLM_BF16) return dispatch_gemv_mfma<bf16_t>(epilogue, p, stream);

@@ -127,8 +127,17 @@ def _req(t, dtype=None, what="tensor"):
 
 
 _workspaces = {}   # (device index, stream handle) -> workspace
+_ws_streams = {}   # (device index, stream handle) -> the torch stream object the workspace belongs to
 _ws_probes = {}    # (device index, stream handle) -> (pinned int32[1], event): the error word as of the previous check
 _ERR_WORD_BYTE = 1000 * 4   # kSkErrWord of csrc/gemm_common.h
+
+
+def _dev_index(device):
+    """device ordinal of `device` (None / torch.device("cuda") without an index -> the current device)"""
+    if device is None:
+        return torch.cuda.current_device()
+    idx = torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
 
 
 def gemm_workspace(device):
@@ -136,12 +145,13 @@ def gemm_workspace(device):
     assume the launches sharing a workspace are ordered (stllm_hip.h: "private to the launch stream"), so there is ONE PER
     (device, stream): a GEMM issued from a second torch stream — e.g. next to an RCCL collective — gets its own flags and slabs
     instead of racing the first stream's exchanges."""
-    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    dev = _dev_index(device)
     key = (dev, int(torch.cuda.current_stream(dev).cuda_stream))
     ws = _workspaces.get(key)
     if ws is None:
         ws = torch.zeros(int(lib().stllm_gemm_workspace_bytes()), dtype=torch.uint8, device=f"cuda:{dev}")
         _workspaces[key] = ws
+        _ws_streams[key] = torch.cuda.current_stream(dev)
     return ws
 
 
@@ -178,7 +188,8 @@ def gemm_w4_plan(M, N, K, heavy=0, shape=34):
 
 def gemm_workspace_ok(device=None):
     """Synchronises and returns True when no split-K GEMM exchange on this device ever timed out (see stllm_hip.h)."""
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = _dev_index(device)
+    torch.cuda.synchronize(dev)   # device-wide: the workspaces belong to different streams (one per (device, stream))
     ok = True
     for (d, _), ws in list(_workspaces.items()):
         if d == dev:
@@ -195,7 +206,7 @@ def gemm_workspace_check(device=None, wait=False):
     enqueues a fresh one behind the work submitted so far — a forward() that went wrong is reported by the next call."""
     if not torch.cuda.is_available():
         return
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = _dev_index(device)
     if wait:
         if not gemm_workspace_ok(dev):
             raise RuntimeError(lib().stllm_last_error().decode())
@@ -211,9 +222,10 @@ def gemm_workspace_check(device=None, wait=False):
             probe = None
         if probe is None:
             host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            host.copy_(ws[_ERR_WORD_BYTE: _ERR_WORD_BYTE + 4].view(torch.int32), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            with torch.cuda.stream(_ws_streams[key]):   # behind the GEMMs of THAT stream, not of whichever stream is current here
+                host.copy_(ws[_ERR_WORD_BYTE: _ERR_WORD_BYTE + 4].view(torch.int32), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
             _ws_probes[key] = (host, ev)
 
 

@@ -157,7 +157,9 @@ class STLLMModel(Blip2Base):
                     all_t = [qtext] * frames.shape[0] if isinstance(qtext, str) else [t for t in qtext for _ in range(T)]
                     t_local = all_t[s0: s0 + fr.shape[0]]
                 return self._encode_frames(fr, t_local, T, dt)
-            self._fp_local_clips = not parallel.gather_needed(frames.shape[0], T, world, load)
+            # image batches (T == 1 -> use_image) are not clip-sharded by forward(): every rank prefills the whole batch and so needs
+            # every image's tokens — the collective may only be skipped on the video path
+            self._fp_local_clips = (not use_image) and not parallel.gather_needed(frames.shape[0], T, world, load)
             if self._fp_local_clips:   # this rank's frames ARE the clips it prefills (one clip per GPU): nothing to exchange
                 s0, e0 = parallel.frame_range(frames.shape[0], rank, world, load)
                 tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, 32, 4096), dtype=torch.float32, device=image.device)

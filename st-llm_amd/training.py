@@ -379,6 +379,12 @@ class AdamW:
                 self.gflat[off: off + p.numel()] = g.reshape(-1)
         lo = self.rank * self.shard
         if self.world > 1:
+            # presence is a property of the AVERAGED gradient: a parameter that got a gradient on ANY rank (mixed image / video
+            # batches, a mask drawn on one rank only) is updated on the rank that owns its shard and its step count advances on
+            # every rank alike — torch DDP semantics; a per-rank view would skip updates and let the bias corrections diverge
+            pm = torch.tensor([1 if x else 0 for x in present], dtype=torch.int32, device=self.gflat.device)
+            dist.all_reduce(pm, op=dist.ReduceOp.MAX, group=self.group)
+            present = [bool(x) for x in pm.tolist()]
             gshard = torch.empty(self.shard, device=self.gflat.device, dtype=torch.float32)
             if dist.get_backend(self.group) == "gloo":          # gloo has no reduce_scatter: all-reduce + slice (tests only)
                 dist.all_reduce(self.gflat, group=self.group)

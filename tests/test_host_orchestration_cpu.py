@@ -164,6 +164,16 @@ def _fp_worker(rank, world, port, cfg_names, q):
                 out2 = model(samples=samples2)
             assert model.model.stllm_model._fp_local_clips
             q.put((cfg_name + "/one_clip_per_rank", rank, model.model.stllm_model.owned_clips, out2.logits.clone(), single2))
+            # image batch (T == 1 -> use_image): forward() does not shard images by clip, every rank prefills the whole batch and
+            # must therefore hold EVERY image's tokens — the all-gather may not be skipped although ranges == "clips" 
+            samples3, _ = make_inputs(2, 1, cfg["qformer_text_input"])
+            with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+                model.model.stllm_model.set_frame_parallel(0, 1)
+                single3 = model(samples=samples3).logits.clone()
+                model.model.stllm_model.set_frame_parallel(rank, world)
+                out3 = model(samples=samples3)
+            assert not model.model.stllm_model._fp_local_clips
+            q.put((cfg_name + "/image_batch", rank, None, out3.logits.clone(), single3))
         del model
     dist.barrier()
     dist.destroy_process_group()
@@ -184,7 +194,7 @@ def test_frame_parallel_model_matches_single_process():
     for p in procs:
         p.start()
     res = []
-    n_results = world * (len(cfg_names) + 1)      # + the one-clip-per-rank case of the eva_clip_g config
+    n_results = world * (len(cfg_names) + 2)      # + the one-clip-per-rank and the image-batch case of the eva_clip_g config
     while len(res) < n_results:      # a worker that died must fail the test, not hang it
         try:
             res.append(q.get(timeout=10))
@@ -208,6 +218,10 @@ def test_frame_parallel_model_matches_single_process():
                 # (the contract backend's CPU BLAS blocks a 1-clip and a 3-clip GEMM differently: a few fp32 ulps, not bits)
                 assert torch.equal(a[:n], b[:n]) or (a[:n] - b[:n]).abs().max() <= 5e-5, f"{cfg_name}: rank {rank} clip {c}"
         assert sorted(seen) == [0, 1, 2], cfg_name
+    img = [r for r in res if r[0].endswith("/image_batch")]
+    assert len(img) == world
+    for name, rank, _, logits, single in img:     # every rank: the full batch, every image paired with ITS prompt and answer
+        assert logits.shape == single.shape and (logits - single).abs().max() <= 5e-5, f"{name}: rank {rank}"
     extra = [r for r in res if r[0].endswith("/one_clip_per_rank")]
     assert len(extra) == world
     for name, rank, own, logits, single in extra:

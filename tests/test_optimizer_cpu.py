@@ -94,6 +94,59 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _presence_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stllm_amd import training
+    named = _params()
+    with _cpu_backend.installed():
+        opt = training.AdamW(named, lr=3e-3, weight_decay=0.01, max_grad_norm=0.5, group=dist.group.WORLD, world_size=world, rank=rank)
+        for step in range(3):
+            g = _grads(named, 10 * step + rank)
+            if rank == 1:
+                g.pop("p1")                      # e.g. an image batch on rank 1: no pooling-MLP gradient there
+                g.pop("p3", None) if step == 1 else None
+            if step == 2:
+                g.pop("p2")                      # nobody has p2 in the last step: skipped everywhere
+            opt.step(g)
+    q.put((rank, [p.detach().numpy().copy() for _, p in named], list(opt.steps)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero1_gradient_presence_is_global():
+    """A parameter with a gradient on ONE rank only (mixed image / video batches): the averaged gradient is non-zero, so the owner
+    of its shard must apply it and every rank must advance that parameter's step count — as torch DDP does."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_presence_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from stllm_amd import training
+    named = _params()
+    with _cpu_backend.installed():
+        opt = training.AdamW(named, lr=3e-3, weight_decay=0.01, max_grad_norm=0.5)
+        for step in range(3):
+            ga, gb = _grads(named, 10 * step), _grads(named, 10 * step + 1)
+            gb["p1"] = torch.zeros_like(gb["p1"])
+            if step == 1:
+                gb["p3"] = torch.zeros_like(gb["p3"])
+            avg = {n: (ga[n] + gb[n]) / 2 for n in ga}
+            if step == 2:
+                avg.pop("p2")
+            opt.step(avg)
+    for rank, params, steps in res:
+        assert steps == [3, 3, 2, 3] == opt.steps, (rank, steps)
+        for got, (n, want) in zip(params, named):
+            assert torch.allclose(torch.from_numpy(got), want, rtol=1e-5, atol=1e-6), (rank, n)
+
+
 def test_zero1_sharded_step_matches_single_process():
     world = 2
     ctx = mp.get_context("spawn")
