@@ -165,6 +165,8 @@ class STLLMModel(Blip2Base):
                 tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, 32, 4096), dtype=torch.float32, device=image.device)
             else:
                 tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load)
+            if getattr(self, "_fp_keep_tokens", False):   # bench.py's one-off check of the gathered block against a single-GPU encode
+                self._fp_last_tokens = tokens
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
             atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
             return inputs_llama, atts_llama, use_image

@@ -31,8 +31,19 @@ def test_bench_self_spawns_two_ranks(config, scaling, batch):
     assert "frame-parallel x2" in res["config"]["parallelism"] and "DRY RUN" in res["data"]
     assert res["loss"] == res["loss"], "rank 0 owns clip 0: its loss must be a number"
     assert res["allgather_in_step"] == (config == "c3")   # one clip per GPU (c2): the collective carries nothing and is skipped
+    assert res["rccl_ranks"] == 2
     if config == "c3":
         assert res["config"]["video_tokens_per_clip"] == 2 * 32 and "residual" in res["config"]["workload"]   # R clamped to the 2 frames of the dry run
+        assert "frame_parallel" not in res            # the c3 line IS the frame-parallel experiment
+    else:
+        # the driver's `bench.py --gpus N` (no --config) must carry the north star's experiment: c3 strong scaling, rank 0 alone first, then
+        # all ranks with the all-gather inside the step, and the gathered block checked against the single-GPU encode
+        fp = res["frame_parallel"]
+        assert fp["config"] == "c3" and fp["scaling"] == "strong" and fp["allgather_in_step"] is True
+        assert fp["ms_per_step_1gpu"] > 0 and fp["ms_per_step"] > 0 and abs(fp["speedup"] - fp["ms_per_step_1gpu"] / fp["ms_per_step"]) < 1e-2
+        assert fp["frames_per_rank"] == [4, 4] and fp["clips_per_rank"] == [2, 2] and fp["allgather_us"] > 0
+        assert fp["gathered_block_bit_identical"] is True and fp["gathered_block_max_abs_diff"] == 0.0
+        assert fp["allgather_bytes_per_rank"] == 4 * 32 * 4096 * 4
 
 
 def test_bench_launcher_environment_is_honoured(monkeypatch):

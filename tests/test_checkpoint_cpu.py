@@ -150,3 +150,20 @@ def test_eva_pos_embed_interpolation_matches_reference():
     vit.load_state_dict(sd)
     assert vit.pos_embed.shape == (1, 257, 1408)
     assert np.abs(vit.pos_embed.detach().numpy()[..., :24] - g["down.out"]).max() <= 2e-6 and float(vit.pos_embed[..., 24:].abs().max()) == 0.0
+
+
+def test_checkpoint_files_to_forward_on_contract_backend(tmp_path):
+    """the -m gpu test `test_checkpoint_io_on_device` with the kernels replaced by the contract backend: the same files, the same loader,
+    the same oracle comparison (tests/_ckpt_case.py) — keeps the case itself honest without a GPU."""
+    import _ckpt_case
+    import _cpu_backend
+    from stllm_amd import runtime
+
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+            yield
+    err, loss_err = _ckpt_case.run(tmp_path, "cpu", ctx)
+    assert err <= 5e-4 and loss_err <= 1e-4, (err, loss_err)

@@ -698,6 +698,8 @@ ATTN_CASES = [  # name, B, H, Sq, Skv, D, causal, kv_len
     ("llama_576", 1, 32, 576, 576, 128, True, None),              # the benchmarked prefill: 4 query tiles x 2 key-split waves per workgroup
     ("llama_576_b2", 2, 32, 576, 576, 128, True, [576, 400]),     # >= 128 workgroups already with 12 query tiles x 1 wave
     ("llama_noncausal", 2, 4, 300, 300, 128, False, [300, 170]),
+    ("llama_1100", 1, 32, 1100, 1100, 128, True, None),           # BASELINE configs[3]: the un-masked pass of the MVM forward at T = 32 (S ~ 1100)
+    ("llama_1100_ragged", 2, 32, 1100, 1100, 128, True, [1100, 640]),
 ]
 
 

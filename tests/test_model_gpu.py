@@ -231,6 +231,84 @@ def test_config5_minigpt4base_btadapter_vs_oracle():
     assert abs(out.loss.item() - ref["loss"].item()) <= 1e-3
 
 
+def test_config4_mvm_forward_t32_vs_oracle():
+    """BASELINE configs[3] at its stated T: T = 32 frames, 'all' pooling (L = 1024 visual tokens), injected mask at rate 0.5 (512 kept),
+    MVM branch on (st_llm.py:71-91, 480-493): the masked pass prefills S ~ 560 positions, the un-masked pass S ~ 1100 — the longest causal
+    prefill of any config (launch shapes of the attention windows and the GEMM plans at M ~ 1100), both gathers, mvm_decoder + cosine loss.
+    ViT / Q-Former / LLM at depth 2 (full width) so that the oracle runs in seconds; verify mode within the north-star bar, then the
+    bf16 kernels on the same shapes."""
+    from stllm_amd import hip, runtime
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=True,
+               mvm_decode=True, qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=2, qf_layers=2, llm_layers=2)
+    B, Tn = 1, 32
+    g = torch.Generator().manual_seed(5)
+    ids = lambda n: torch.randint(3, 32000, (n,), generator=g).tolist()
+    before, after, answer = [ids(7)], [ids(40)], [ids(15)]     # img_start = 8 = BOS + 7 ids, as the reference assumes (st_llm.py:71)
+    s = lambda r: " ".join(map(str, r))
+    image = T("input.video32", (B, Tn, 3, 224, 224))
+    np.random.seed(13)
+    mask = torch.from_numpy(O.random_masking_generator(Tn * 32, 0.5, B))
+    samples = {"image": image.cuda(), "instruction_input": [f"{s(before[0])}<ImageHere>{s(after[0])}"], "answer": [s(answer[0])], "mask": mask}
+    sd = sd_from({**shapes.stllm_model_shapes(2, 2, False, "all", True), **shapes.llama_shapes(2)})
+    ref = O.stllm_forward({"image": image, "before_ids": before, "after_ids": after, "answer_ids": [a + [2] for a in answer], "mask": mask},
+                          sd, dict(cfg, pad_id=0, bos_id=1))
+    sm = model.model.stllm_model
+    with runtime.use_dtype("fp32"):
+        ie, am, ue, ua, tg = sm(samples)
+        out = model(samples=samples)
+    assert (sm.img_len, sm.mask_img_len) == (1024, 512)
+    assert ie.shape[1] == 1 + 7 + 512 + 40 + 16 and ue.shape[1] == 1 + 7 + 1024 + 40 + 16
+    assert np.array_equal(tg.cpu().numpy(), ref["targets"].numpy()) and np.array_equal(am.cpu().numpy(), ref["attention_mask"].numpy())
+    err = float((out.logits.cpu() - ref["logits"]).abs().max())
+    print(f"\n[config4 T=32 fp32] S = {ie.shape[1]} / {ue.shape[1]}: logits max-abs err {err:.3e}; loss {out.loss.item():.5f} vs {ref['loss'].item():.5f} "
+          f"(loss_mvm {ref['loss_mvm'].item():.5f})")
+    assert err <= 1e-2
+    assert abs(out.loss.item() - ref["loss"].item()) <= 1e-3
+    scale = float(ref["logits"].abs().max())
+    with runtime.use_dtype("bf16"):
+        out16 = model(samples=samples)
+    err16 = float((out16.logits.cpu() - ref["logits"]).abs().max())
+    print(f"[config4 T=32 bf16] logits max-abs err {err16:.3e} (abs-max {scale:.2f}); loss {out16.loss.item():.5f}")
+    assert err16 <= 5e-2 * scale and abs(out16.loss.item() - ref["loss"].item()) <= 0.05
+    assert hip.gemm_workspace_ok()
+
+
+def test_config5_btadapter_full_depth_t16_vs_oracle():
+    """BASELINE configs[4] backbone at its stated size: EVA-CLIP-g 39 blocks with the BT-Adapter on blocks 36-38 (eva_btadapter.py:
+    147-184: temporal attention over T per patch + spatial block, non-zero temporal_fc), one clip of T = 16 frames, verify mode vs the
+    oracle.  (The full model around it at reduced depth: test_config5_minigpt4base_btadapter_vs_oracle.)"""
+    from stllm_amd import runtime
+    from stllm_amd.models.eva_btadapter import create_eva_btadapter
+    m = fill(create_eva_btadapter(depth=39, adapter_depth=3, device="cuda"), "visual_encoder.")
+    x5 = T("input.video16", (1, 16, 3, 224, 224))
+    sd = sd_from(shapes.btadapter_shapes(39, 3))
+    torch.set_num_threads(min(64, torch.get_num_threads() if torch.get_num_threads() > 8 else (__import__("os").cpu_count() or 8)))
+    want = O.btadapter_forward(x5, sd, "visual_encoder.", 3)
+    with runtime.use_dtype("fp32"):
+        got = m(x5.cuda())
+    assert got.shape == want.shape == (16, 257, 1408)
+    scale = float(want.abs().max())
+    err = float((got.cpu() - want).abs().max())
+    print(f"\n[config5 backbone 39 blocks T=16 fp32] max-abs err {err:.3e} (abs-max {scale:.2f})")
+    assert err <= 2e-4 * scale and err <= 1e-2
+    with runtime.use_dtype("bf16"):
+        got16 = m(x5.cuda())
+    err16 = float((got16.float().cpu() - want).abs().max())
+    print(f"[config5 backbone bf16] max-abs err {err16:.3e}")
+    assert err16 <= 8e-2 * scale
+
+
+def test_checkpoint_io_on_device(tmp_path):
+    """§8(f4) with the HIP path behind it (VERDICT r02 missing #1): see tests/_ckpt_case.py — sharded LLM directory + `ckpt` file with
+    `llm_proj.*`, 32001-row tables and a 24 x 24-grid pos_embed -> from_config(device="cuda") -> verify-mode forward == oracle."""
+    import _ckpt_case
+    from stllm_amd import runtime
+    err, loss_err = _ckpt_case.run(tmp_path, "cuda", lambda: runtime.use_dtype("fp32"))
+    print(f"\n[checkpoint on device fp32] logits max-abs err {err:.3e}; loss err {loss_err:.3e}")
+    assert err <= 1e-3 and loss_err <= 1e-3
+
+
 def test_config3_global_local_t64_vs_oracle():
     """BASELINE config 3 shape: B=2 clips x T=64 frames, global-local module R=16 (residual), text Q-Former — pooling and
     token-block assembly at full T (ViT depth 1 so that it runs in seconds), verify mode vs oracle."""
@@ -331,8 +409,9 @@ def test_c2_full_size_vs_reference():
             assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
             assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
             assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
-    assert res["fp16"][0] <= 0.05 and res["fp16"][1] >= 0.98, res["fp16"]
-    assert res["bf16"][0] <= 0.3 and res["bf16"][1] >= 0.88, res["bf16"]
+    # measured in round 2 at this size: bf16 0.244 / 0.936, fp16 0.025 / 0.99 -> measured + 20 %
+    assert res["fp16"][0] <= 0.03 and res["fp16"][1] >= 0.985, res["fp16"]
+    assert res["bf16"][0] <= 0.29 and res["bf16"][1] >= 0.92, res["bf16"]
     assert abs(res["bf16"][2] - g["loss"][0]) <= 0.05 and abs(res["fp16"][2] - g["loss"][0]) <= 0.01
 
 
