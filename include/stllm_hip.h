@@ -148,6 +148,59 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
 int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);
 
+/* HIP-event timing of stllm_gemm launches on their launch stream, per calling thread (bench.py's roofline leg; also sees the launches of
+ * the whole-stack entry points below).  mode 0 off | 1 every launch | 2 only launches whose kernel symbol — learned per (dtype, epilogue,
+ * act, M, N, K) while mode 1 was on — equals target_symbol.  Every call starts a new, empty session.  _read synchronises record i's end
+ * event and returns its kernel symbol (stllm_last_kernel naming), duration, algorithmic FLOPs (2 M N K) and shape. */
+int stllm_gemm_profile(int mode, const char* target_symbol);
+int stllm_gemm_profile_count(void);
+int stllm_gemm_profile_read(int i, char* symbol, int symbol_cap, float* ms, double* flops, int* mnk3 /* M, N, K or NULL */);
+
+/* =========================================================================================================================
+ * Whole-stack entry points: one host call issues every launch of a layer stack, through the entry points of this header
+ * with the arguments the per-op host code passes (bit-identical results; ~540 host round trips per step become a handful).
+ * All weight pointers are device pointers to tensors packed as for stllm_gemm (st-llm_amd/pack.py); ld_* = row stride in elements.
+ * ========================================================================================================================= */
+
+/* one EVA ViT block (eva_vit.py:157-180: norm1, attn.qkv + (q_bias, 0, v_bias), attn.proj, norm2, mlp.fc1, mlp.fc2) */
+typedef struct {
+  const float* n1w; const float* n1b; float e1;
+  const void* wqkv; int64_t ld_qkv; const float* bqkv;     /* [3 dim, dim], bias f32 [3 dim] = (q_bias, 0, v_bias) (eva_vit.py:120-124) */
+  const void* wproj; int64_t ld_proj; const float* bproj;
+  const float* n2w; const float* n2b; float e2;
+  const void* wfc1; int64_t ld_fc1; const float* bfc1;     /* [hidden, dim] */
+  const void* wfc2; int64_t ld_fc2; const float* bfc2;     /* [dim, hidden] */
+} stllm_vit_block_weights;
+typedef struct {
+  int dtype; int n_seq; int seq_len; int num_heads; int dim; int hidden;
+  float* x; int64_t ldx;                       /* fp32 residual stream [n_seq * seq_len, dim], updated in place */
+  void* scratch; int64_t scratch_bytes;        /* >= stllm_vit_blocks_scratch_bytes(...), 256-byte aligned, no initialisation */
+  void* workspace; int64_t workspace_bytes;    /* the stllm_gemm workspace of the launch stream */
+} stllm_vit_blocks_args;
+int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden);
+/* VisionTransformer.forward_features' block loop (eva_vit.py:336-339; Block.forward :173-180) for n_blocks consecutive blocks */
+int stllm_vit_blocks(const stllm_vit_blocks_args* args, const stllm_vit_block_weights* blocks, int n_blocks, void* stream);
+
+/* one HF LlamaDecoderLayer (spec modeling_llama_mem.py:61-316): RMSNorm weights, fused [q | k | v] rows in the packed RoPE layout,
+ * o_proj, packed [32 gate | 32 up] rows, down_proj; kv_cache: NULL or this layer's [B, cache_max_len, 3 hidden] cache buffer */
+typedef struct {
+  const float* ln1; const void* wqkv; int64_t ld_qkv; const void* wo; int64_t ld_o;
+  const float* ln2; const void* wgu; int64_t ld_gu; const void* wdown; int64_t ld_down;
+  void* kv_cache;
+} stllm_llama_layer_weights;
+typedef struct {
+  int dtype; int B; int S; int n_heads; int hidden; int inter; float eps;
+  float* x; int64_t ldx;                       /* fp32 residual stream [B * S, hidden], updated in place */
+  const float* rope_cos; const float* rope_sin;/* f32 [S, 64] */
+  const int32_t* kv_len;                       /* int32 [B] valid lengths of right-padded sequences, or NULL */
+  int64_t cache_max_len;                       /* 0: no KV cache */
+  void* scratch; int64_t scratch_bytes;        /* >= stllm_llama_layers_scratch_bytes(...) */
+  void* workspace; int64_t workspace_bytes;
+} stllm_llama_layers_args;
+int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, int inter);
+/* the decoder-layer loop of the PREFILL (st_llm.py:56-92 -> HF LlamaModel.forward, use_cache False or filling a fresh cache) */
+int stllm_llama_layers(const stllm_llama_layers_args* args, const stllm_llama_layer_weights* layers, int n_layers, void* stream);
+
 /*
  * Decode attention: ONE query row per (batch, head) against Skv cached keys (the one-token step of generate(), SURVEY §8f
  * rank 1; HF LlamaAttention with past_key_values, spec modeling_llama_mem.py:172-248).  HBM-bound: the keys are split over

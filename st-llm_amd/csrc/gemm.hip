@@ -979,6 +979,9 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
 
 }  // namespace
 
+int stllm_prof_begin(const stllm_gemm_args* a, void* stream);     // profile.cpp
+void stllm_prof_end(int idx, const stllm_gemm_args* a, void* stream);
+
 extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   STLLM_CHECK_ARG(a != nullptr, "stllm_gemm: null args");
@@ -1029,11 +1032,15 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   p.nx = a->a_norm_x; p.nx_ld = a->a_norm_ldx; p.ngamma = a->a_norm_gamma; p.neps = a->a_norm_eps;
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
   p.o_rpb = a->o_rows_per_batch; p.o_bs = a->o_batch_stride;
+  const int prof_rec = stllm_prof_begin(a, stream_);   // profile.cpp: HIP events around this launch when the caller asked for them
+  int rc;
   switch (a->dtype) {
-    case STLLM_BF16: return dispatch_epi<bf16_t>(a, p, stream);
-    case STLLM_F16: return dispatch_epi<f16_t>(a, p, stream);
-    default: return dispatch_epi<float>(a, p, stream);
+    case STLLM_BF16: rc = dispatch_epi<bf16_t>(a, p, stream); break;
+    case STLLM_F16: rc = dispatch_epi<f16_t>(a, p, stream); break;
+    default: rc = dispatch_epi<float>(a, p, stream); break;
   }
+  stllm_prof_end(prof_rec, a, stream_);
+  return rc;
 }
 
 extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_) {

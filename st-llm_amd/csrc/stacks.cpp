@@ -1,0 +1,169 @@
+// Whole-stack entry points (SURVEY.md §8b "whole-stack entry points taking a packed-weights handle"): the ViT block loop and the Llama
+// decoder-layer loop issued from ONE C call each, so that a step costs a handful of host calls instead of ~540 ctypes round trips and
+// the launch queue never runs dry behind the host.  Pure host code: every kernel goes through the same public entry points
+// (stllm_layernorm / stllm_rmsnorm / stllm_gemm / stllm_attention) with the same arguments the per-op Python path passes —
+// results are bit-identical to that path by construction.
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/stllm_hip.h"
+
+void stllm_set_error(const char* fmt, ...);
+
+namespace {
+
+inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
+inline int esize(int dtype) { return dtype == STLLM_F32 ? 4 : 2; }
+
+struct Carver {
+  char* base;
+  int64_t off = 0, cap;
+  Carver(void* p, int64_t bytes) : base(reinterpret_cast<char*>(p)), cap(bytes) {}
+  void* take(int64_t bytes) {
+    void* r = base + off;
+    off += up256(bytes);
+    return r;
+  }
+  bool ok() const { return off <= cap; }
+};
+
+stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes) {
+  stllm_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.dtype = dtype;
+  g.workspace = ws;
+  g.workspace_bytes = ws_bytes;
+  return g;
+}
+
+}  // namespace
+
+#define STACK_TRY(call)          \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != STLLM_OK) return rc_; \
+  } while (0)
+
+extern "C" int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden) {
+  if (n_seq <= 0 || seq_len <= 0 || dim <= 0 || hidden <= 0) return -1;
+  const int64_t M = (int64_t)n_seq * seq_len, e = esize(dtype);
+  return up256(M * dim * e) * 2 + up256(M * 3 * dim * e) + up256(M * hidden * e);
+}
+
+// eva_vit.py:173-180 (Block.forward, gamma_1 / gamma_2 None) x n_blocks on the flat fp32 stream, in place:
+//   LN -> [qkv GEMM + (q_bias, 0, v_bias)] -> attention (scale head_dim^-0.5) -> [proj GEMM + bias + residual] -> LN ->
+//   [fc1 GEMM + bias + GELU] -> [fc2 GEMM + bias + residual]
+extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_block_weights* blocks, int n_blocks, void* stream) {
+  if (!a || (!blocks && n_blocks > 0) || n_blocks < 0) { stllm_set_error("stllm_vit_blocks: null arguments"); return STLLM_ERR_BAD_SHAPE; }
+  if (a->dim % a->num_heads != 0 || !a->x || !a->scratch) { stllm_set_error("stllm_vit_blocks: bad dims / null buffers"); return STLLM_ERR_BAD_SHAPE; }
+  const int64_t need = stllm_vit_blocks_scratch_bytes(a->dtype, a->n_seq, a->seq_len, a->dim, a->hidden);
+  if (need < 0 || a->scratch_bytes < need) {
+    stllm_set_error("stllm_vit_blocks: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const int M = a->n_seq * a->seq_len, D = a->dim, hd = D / a->num_heads, e = esize(a->dtype);
+  Carver c(a->scratch, a->scratch_bytes);
+  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* qkv = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
+  char* g1 = reinterpret_cast<char*>(c.take((int64_t)M * a->hidden * e));
+  float scale = 1.0f;
+  {   // hd ** -0.5 exactly as the host path computes it (Python float -> float32)
+    double s = 1.0;
+    s = 1.0 / __builtin_sqrt((double)hd);
+    scale = (float)s;
+  }
+  for (int b = 0; b < n_blocks; ++b) {
+    const stllm_vit_block_weights& w = blocks[b];
+    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
+    g.out = qkv; g.ldo = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
+    STACK_TRY(stllm_gemm(&g, stream));
+    const int64_t rs = 3 * D, bs = (int64_t)a->seq_len * rs;
+    STACK_TRY(stllm_attention(a->dtype, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
+                              (int64_t)a->seq_len * D, D, a->n_seq, a->num_heads, a->seq_len, a->seq_len, hd, scale, 0, nullptr, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wproj; g.ldw = w.ld_proj; g.bias = w.bproj;
+    g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
+    STACK_TRY(stllm_gemm(&g, stream));
+    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
+    g.out = g1; g.ldo = a->hidden; g.M = M; g.N = a->hidden; g.K = D;
+    STACK_TRY(stllm_gemm(&g, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_RESID; g.A = g1; g.lda = a->hidden; g.W = w.wfc2; g.ldw = w.ld_fc2; g.bias = w.bfc2;
+    g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->hidden;
+    STACK_TRY(stllm_gemm(&g, stream));
+  }
+  return STLLM_OK;
+}
+
+extern "C" int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, int inter) {
+  if (B <= 0 || S <= 0 || hidden <= 0 || inter <= 0) return -1;
+  const int64_t M = (int64_t)B * S, e = esize(dtype);
+  return up256(M * hidden * e) * 2 + up256(M * 3 * hidden * e) + up256(M * inter * e);
+}
+
+// HF LlamaDecoderLayer x n_layers in prefill form (spec modeling_llama_mem.py:61-316) on the flat fp32 stream, in place:
+//   RMSNorm -> [fused QKV GEMM + rotate-half RoPE] -> causal attention (+ right-padding kv_len) -> [o_proj + residual] -> RMSNorm ->
+//   [gate/up GEMM + SiLU(gate) * up] -> [down_proj + residual].   With kv_cache pointers the fused QKV rows of layer l are written
+//   into its cache buffer [B, cache_max_len, 3 * hidden] (rows (b, s) at b * cache_max_len + s) and attended in place.
+extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_llama_layer_weights* layers, int n_layers, void* stream) {
+  if (!a || (!layers && n_layers > 0) || n_layers < 0) { stllm_set_error("stllm_llama_layers: null arguments"); return STLLM_ERR_BAD_SHAPE; }
+  if (!a->x || !a->scratch || !a->rope_cos || !a->rope_sin || a->hidden % a->n_heads != 0) {
+    stllm_set_error("stllm_llama_layers: bad dims / null buffers");
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const int64_t need = stllm_llama_layers_scratch_bytes(a->dtype, a->B, a->S, a->hidden, a->inter);
+  if (need < 0 || a->scratch_bytes < need) {
+    stllm_set_error("stllm_llama_layers: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const int M = a->B * a->S, D = a->hidden, hd = D / a->n_heads, e = esize(a->dtype);
+  if (a->cache_max_len != 0 && (a->cache_max_len < a->S || a->kv_len != nullptr)) {
+    stllm_set_error("stllm_llama_layers: the KV cache needs max_len >= S and equal-length sequences");
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  Carver c(a->scratch, a->scratch_bytes);
+  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* qkv_s = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
+  char* gu = reinterpret_cast<char*>(c.take((int64_t)M * a->inter * e));
+  const float scale = (float)(1.0 / __builtin_sqrt((double)hd));
+  for (int l = 0; l < n_layers; ++l) {
+    const stllm_llama_layer_weights& w = layers[l];
+    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln1, a->eps, h, D, nullptr, 0, M, D, stream));
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv;
+    g.aux0 = a->rope_cos; g.aux1 = a->rope_sin; g.rope_seq = a->S; g.rope_cols = 2 * D; g.M = M; g.N = 3 * D; g.K = D; g.ldo = 3 * D;
+    char* qkv = qkv_s;
+    int64_t bs = (int64_t)a->S * 3 * D;
+    if (a->cache_max_len != 0) {
+      if (!w.kv_cache) { stllm_set_error("stllm_llama_layers: layer %d has no cache buffer", l); return STLLM_ERR_BAD_SHAPE; }
+      qkv = reinterpret_cast<char*>(w.kv_cache);
+      bs = a->cache_max_len * 3 * D;
+      g.o_rows_per_batch = a->S; g.o_batch_stride = bs;
+    }
+    g.out = qkv;
+    STACK_TRY(stllm_gemm(&g, stream));
+    const int64_t rs = 3 * D;
+    STACK_TRY(stllm_attention(a->dtype, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
+                              (int64_t)a->S * D, D, a->B, a->n_heads, a->S, a->S, hd, scale, 1, a->kv_len, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wo; g.ldw = w.ld_o;
+    g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
+    STACK_TRY(stllm_gemm(&g, stream));
+    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln2, a->eps, h, D, nullptr, 0, M, D, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = D; g.W = w.wgu; g.ldw = w.ld_gu;
+    g.out = gu; g.ldo = a->inter; g.M = M; g.N = 2 * a->inter; g.K = D;
+    STACK_TRY(stllm_gemm(&g, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g.epilogue = STLLM_EPI_RESID; g.A = gu; g.lda = a->inter; g.W = w.wdown; g.ldw = w.ld_down;
+    g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->inter;
+    STACK_TRY(stllm_gemm(&g, stream));
+  }
+  return STLLM_OK;
+}

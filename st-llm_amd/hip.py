@@ -23,7 +23,8 @@ EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_
            "stllm_attention", "stllm_gather_rows", "stllm_mean_t", "stllm_vit_cls_rows", "stllm_cosine_rows",
            "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_gemm_w4_plan", "stllm_set_option",
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
-           "stllm_attention_decode"]
+           "stllm_attention_decode", "stllm_gemm_profile", "stllm_gemm_profile_count", "stllm_gemm_profile_read",
+           "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers"]
 
 
 def torch_dtype(d):
@@ -45,6 +46,34 @@ class GemmArgs(ctypes.Structure):
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float)]
+
+
+class VitBlockWeights(ctypes.Structure):
+    _fields_ = [("n1w", c_void_p), ("n1b", c_void_p), ("e1", c_float),
+                ("wqkv", c_void_p), ("ld_qkv", c_int64), ("bqkv", c_void_p),
+                ("wproj", c_void_p), ("ld_proj", c_int64), ("bproj", c_void_p),
+                ("n2w", c_void_p), ("n2b", c_void_p), ("e2", c_float),
+                ("wfc1", c_void_p), ("ld_fc1", c_int64), ("bfc1", c_void_p),
+                ("wfc2", c_void_p), ("ld_fc2", c_int64), ("bfc2", c_void_p)]
+
+
+class VitBlocksArgs(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("n_seq", c_int), ("seq_len", c_int), ("num_heads", c_int), ("dim", c_int), ("hidden", c_int),
+                ("x", c_void_p), ("ldx", c_int64), ("scratch", c_void_p), ("scratch_bytes", c_int64),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+
+
+class LlamaLayerWeights(ctypes.Structure):
+    _fields_ = [("ln1", c_void_p), ("wqkv", c_void_p), ("ld_qkv", c_int64), ("wo", c_void_p), ("ld_o", c_int64),
+                ("ln2", c_void_p), ("wgu", c_void_p), ("ld_gu", c_int64), ("wdown", c_void_p), ("ld_down", c_int64),
+                ("kv_cache", c_void_p)]
+
+
+class LlamaLayersArgs(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("B", c_int), ("S", c_int), ("n_heads", c_int), ("hidden", c_int), ("inter", c_int), ("eps", c_float),
+                ("x", c_void_p), ("ldx", c_int64), ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("kv_len", c_void_p),
+                ("cache_max_len", c_int64), ("scratch", c_void_p), ("scratch_bytes", c_int64),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")
@@ -87,6 +116,13 @@ def _bind(L, strict=True):
     B("stllm_attention_decode_workspace_bytes", [c_int, c_int, c_int], c_int64)
     B("stllm_attention_decode", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int,
                                  c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p])
+    B("stllm_gemm_profile", [c_int, c_char_p])
+    B("stllm_gemm_profile_count", [])
+    B("stllm_gemm_profile_read", [c_int, c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)])
+    B("stllm_vit_blocks_scratch_bytes", [c_int] * 5, c_int64)
+    B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
+    B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
+    B("stllm_llama_layers", [ctypes.POINTER(LlamaLayersArgs), ctypes.POINTER(LlamaLayerWeights), c_int, c_void_p])
     B("stllm_gemm_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
     B("stllm_gemm_w4_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
     return L
@@ -114,6 +150,30 @@ def _stream():
 
 def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
+
+
+def h2d(t, device):
+    """Host tensor -> device WITHOUT stalling the host: staged through pinned memory and enqueued on the current stream.  A pageable
+    `.to(device)` blocks the host until everything queued before the copy has run — one pipeline bubble (~70 us of idle GPU plus the
+    host's lost lead) per index table; profiles/r03_gaps_before.md counted 8 of them per step."""
+    dev = torch.device(device)
+    if dev.type != "cuda" or t.is_cuda:
+        return t.to(dev)
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
+def host_mask(t):
+    """the host copy that travels with a device-side attention mask (set by the code that built it on the host), else a D2H read"""
+    h = getattr(t, "_stllm_host", None)
+    return h if h is not None else t.to("cpu")
+
+
+def with_host(t_host, device):
+    """device copy of a host tensor that remembers where it came from (see host_mask)"""
+    d = h2d(t_host, device)
+    if d is not t_host:
+        d._stllm_host = t_host
+    return d
 
 
 def _req(t, dtype=None, what="tensor"):
@@ -230,28 +290,47 @@ def gemm_workspace_check(device=None, wait=False):
 
 
 class GemmProfiler:
-    """HIP-event timing of GEMM launches on the launch stream (bench.py roofline leg).
-    mode 'all': time every launch (calibration); mode 'target': only launches whose kernel symbol == target."""
+    """HIP-event timing of GEMM launches on the launch stream (bench.py roofline leg), kept on the C side (stllm_gemm_profile: the events
+    sit inside stllm_gemm, so launches issued by the whole-stack entry points are timed like per-op launches).
+    start_all(): time every launch (calibration); start_target(sym): only launches whose kernel symbol == sym; summary() reads the
+    session's records (synchronising their events): {symbol: {launches, total_ms, flops}}."""
 
     def __init__(self):
-        self.mode, self.target = "all", None
-        self.sym_of = {}      # (dtype, epilogue, M, N, K) -> kernel symbol, learned in 'all' mode
-        self.records = {}     # symbol -> [(start_evt, end_evt, algorithmic_flops)]
+        self.target = None
+
+    def start_all(self):
+        self.target = None
+        _check(lib().stllm_gemm_profile(1, None), "stllm_gemm_profile")
+
+    def start_target(self, sym):
+        self.target = sym
+        _check(lib().stllm_gemm_profile(2, sym.encode()), "stllm_gemm_profile")
+
+    def stop(self):
+        _check(lib().stllm_gemm_profile(0, None), "stllm_gemm_profile")
 
     def summary(self):
+        L = lib()
         out = {}
-        for sym, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            out[sym] = dict(launches=len(recs), total_ms=ms, flops=sum(f for _, _, f in recs))
+        buf = ctypes.create_string_buffer(160)
+        ms, fl, mnk = c_float(), ctypes.c_double(), (c_int * 3)()
+        for i in range(int(L.stllm_gemm_profile_count())):
+            _check(L.stllm_gemm_profile_read(i, buf, 160, ctypes.byref(ms), ctypes.byref(fl), mnk), "stllm_gemm_profile_read")
+            e = out.setdefault(buf.value.decode(), dict(launches=0, total_ms=0.0, flops=0.0, shapes={}))
+            e["launches"] += 1
+            e["total_ms"] += ms.value
+            e["flops"] += fl.value
+            sh = e["shapes"].setdefault(f"{mnk[0]}x{mnk[1]}x{mnk[2]}", dict(launches=0, total_ms=0.0, flops=0.0))
+            sh["launches"] += 1
+            sh["total_ms"] += ms.value
+            sh["flops"] += fl.value
         return out
 
 
-_profiler = None
-
-
 def set_profiler(p):
-    global _profiler
-    _profiler = p
+    """kept for callers of the round-1/2 surface: set_profiler(None) stops a session"""
+    if p is None:
+        GemmProfiler().stop()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -314,20 +393,70 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
     args.M, args.N, args.K = M, N, K
     ws = gemm_workspace(w.device)
     args.workspace, args.workspace_bytes = _p(ws), ws.numel()
-    prof, start = _profiler, None
-    if prof is not None:
-        key = (args.dtype, epilogue, M, N, K)
-        if prof.mode == "all" or prof.sym_of.get(key) == prof.target:
-            start = torch.cuda.Event(enable_timing=True)
-            start.record()
     _check(lib().stllm_gemm(ctypes.byref(args), _stream()), "stllm_gemm")
-    if start is not None:
-        end = torch.cuda.Event(enable_timing=True)
-        end.record()
-        sym = lib().stllm_last_kernel().decode()
-        prof.sym_of[key] = sym
-        prof.records.setdefault(sym, []).append((start, end, 2.0 * M * N * K))
     return out
+
+
+def vit_block_array(blocks):
+    """list of Block.pack() dicts -> (ctypes array of stllm_vit_block_weights, the tensors it points into)"""
+    arr = (VitBlockWeights * len(blocks))()
+    for i, pk in enumerate(blocks):
+        w = arr[i]
+        w.n1w, w.n1b, w.e1 = pk["n1w"].data_ptr(), pk["n1b"].data_ptr(), float(pk["e1"])
+        w.wqkv, w.ld_qkv, w.bqkv = pk["wqkv"].data_ptr(), pk["wqkv"].stride(0), pk["bqkv"].data_ptr()
+        w.wproj, w.ld_proj, w.bproj = pk["wproj"].data_ptr(), pk["wproj"].stride(0), pk["bproj"].data_ptr()
+        w.n2w, w.n2b, w.e2 = pk["n2w"].data_ptr(), pk["n2b"].data_ptr(), float(pk["e2"])
+        w.wfc1, w.ld_fc1, w.bfc1 = pk["wfc1"].data_ptr(), pk["wfc1"].stride(0), pk["bfc1"].data_ptr()
+        w.wfc2, w.ld_fc2, w.bfc2 = pk["wfc2"].data_ptr(), pk["wfc2"].stride(0), pk["bfc2"].data_ptr()
+    return arr
+
+
+def vit_blocks(x, blocks, carr, *, n_seq, seq_len, num_heads, dtype):
+    """All ViT blocks of `blocks` (Block.pack() dicts; carr = vit_block_array(blocks), cached by the caller next to them) on the flat
+    fp32 stream x [n_seq * seq_len, dim], in place — ONE C call (stllm_vit_blocks)."""
+    _req(x, torch.float32, "x")
+    td = torch_dtype(dtype)
+    dim, hidden = x.shape[1], blocks[0]["wfc1"].shape[0]
+    L = lib()
+    need = int(L.stllm_vit_blocks_scratch_bytes(dtype_code(td), n_seq, seq_len, dim, hidden))
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = gemm_workspace(x.device)
+    a = VitBlocksArgs(dtype_code(td), n_seq, seq_len, num_heads, dim, hidden, x.data_ptr(), x.stride(0), scratch.data_ptr(), need,
+                      ws.data_ptr(), ws.numel())
+    _check(L.stllm_vit_blocks(ctypes.byref(a), carr, len(blocks), _stream()), "stllm_vit_blocks")
+    return x
+
+
+def llama_layer_array(layers, cache=None):
+    arr = (LlamaLayerWeights * len(layers))()
+    for i, pk in enumerate(layers):
+        w = arr[i]
+        w.ln1, w.wqkv, w.ld_qkv = pk["ln1"].data_ptr(), pk["wqkv"].data_ptr(), pk["wqkv"].stride(0)
+        w.wo, w.ld_o, w.ln2 = pk["wo"].data_ptr(), pk["wo"].stride(0), pk["ln2"].data_ptr()
+        w.wgu, w.ld_gu = pk["wgu"].data_ptr(), pk["wgu"].stride(0)
+        w.wdown, w.ld_down = pk["wdown"].data_ptr(), pk["wdown"].stride(0)
+        w.kv_cache = cache.qkv[i].data_ptr() if cache is not None else None
+    return arr
+
+
+def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=None, cache=None):
+    """All decoder layers of the PREFILL on the flat fp32 stream x [B * S, hidden], in place — ONE C call (stllm_llama_layers).
+    carr = llama_layer_array(layers, cache)."""
+    _req(x, torch.float32, "x")
+    td = torch_dtype(dtype)
+    hidden, inter = x.shape[1], layers[0]["wdown"].shape[1]
+    L = lib()
+    need = int(L.stllm_llama_layers_scratch_bytes(dtype_code(td), B, S, hidden, inter))
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = gemm_workspace(x.device)
+    cos, sin = rope
+    _req(cos, torch.float32, "rope cos"); _req(sin, torch.float32, "rope sin")
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len")
+    a = LlamaLayersArgs(dtype_code(td), B, S, n_heads, hidden, inter, float(eps), x.data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(),
+                        _p(kv_len), cache.max_len if cache is not None else 0, scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
+    _check(L.stllm_llama_layers(ctypes.byref(a), carr, len(layers), _stream()), "stllm_llama_layers")
+    return x
 
 
 def layernorm(x, gamma, beta, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):

@@ -143,8 +143,15 @@ class VisionTransformer(nn.Module):
     def _features_group(self, x, pk, dt, out):
         n = x.shape[0]
         self.embed_flat(x, pk, dt, out=out)
-        for bp in pk["blocks"]:
-            block_forward(out, bp, n, 257, self.num_heads, dt)
+        from . import llama
+        if not llama.STACK_ENTRY:
+            for bp in pk["blocks"]:
+                block_forward(out, bp, n, 257, self.num_heads, dt)
+            return
+        if "cblocks" not in pk:   # the C-side table of the packed blocks lives next to them (dropped with them on repack)
+            pk["cblocks"] = hip.vit_block_array(pk["blocks"])
+        # eva_vit.py:336-339: the whole block loop is ONE call into the C ABI (stllm_vit_blocks; == block_forward per block, bit for bit)
+        hip.vit_blocks(out, pk["blocks"], pk["cblocks"], n_seq=n, seq_len=257, num_heads=self.num_heads, dtype=dt)
 
     def forward_features_flat(self, x):
         """[N,3,224,224] -> flat fp32 stream [N*257, 1408].  The N frames are split into `frame_streams` groups that run on

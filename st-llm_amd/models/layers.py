@@ -87,7 +87,7 @@ class Embedding(nn.Module):
     def forward(self, ids):
         ids = torch.as_tensor(ids)
         shp = ids.shape
-        idx = (-(ids.reshape(-1).to(torch.int64)) - 1).to(torch.int32).to(self.weight.device)
+        idx = hip.h2d((-(ids.reshape(-1).to(torch.int64)) - 1).to(torch.int32), self.weight.device)
         out = hip.gather_rows(self.weight, idx, src_b=self.weight)
         return out.view(*shp, self.weight.shape[1])
 

@@ -86,6 +86,7 @@ class KVCache:
         self.len = 0
 
 
+STACK_ENTRY = os.environ.get("STLLM_STACK_ENTRY", "1") != "0"   # 0: one C-ABI call per op instead of stllm_llama_layers / stllm_vit_blocks (A/B, tests)
 FUSE_NORM_ROWS = int(os.environ.get("STLLM_DECODE_FUSE_ROWS", "2"))   # decode steps with at most this many rows fuse RMSNorm into the GEMVs
 
 
@@ -100,6 +101,7 @@ class LlamaModel(nn.Module):
         self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps, device)
         self._packed = {}
         self._rope = {}
+        self._carr = {}   # C-side table of the packed layers (+ the cache it points into): rebuilt when either changes
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
@@ -137,17 +139,39 @@ class LlamaModel(nn.Module):
         x = inputs_embeds.reshape(B * S, D).float().clone()
         kv_len = None
         if attention_mask is not None:
-            m = attention_mask.to("cpu").long()
+            m = hip.host_mask(attention_mask).long()   # the assembler built it on the host: no D2H read, no stall
             if not bool((m[:, 1:] <= m[:, :-1]).all()):
                 raise NotImplementedError("only right-padded attention masks occur on this path (st_llm.py:400-404)")
             if int(m.sum()) != m.numel():
-                kv_len = m.sum(dim=1).to(torch.int32).to(dev)
+                kv_len = hip.h2d(m.sum(dim=1).to(torch.int32), dev)
         cos, sin = self.rope(S, dev)
         if cache is not None:
             if kv_len is not None:
                 raise NotImplementedError("KV cache needs equal-length sequences")
             assert cache.batch == B and cache.max_len >= S and cache.qkv[0].dtype == dt
             cache.len = S
+        # the 32-layer loop is ONE call into the C ABI (stllm_llama_layers; == prefill_layer_by_layer, bit for bit); with a cache the
+        # fused QKV rows of every layer are written straight into its cache buffer (rows (b, s) at b * max_len + s)
+        if cache is not None:
+            carr = hip.llama_layer_array(layers, cache)       # once per generate(): not worth caching (and it would pin the cache)
+        else:
+            if self._carr.get("layers") is not layers:
+                self._carr = {"layers": layers, "carr": hip.llama_layer_array(layers)}
+            carr = self._carr["carr"]
+        if STACK_ENTRY:
+            hip.llama_layers(x, layers, carr, B=B, S=S, n_heads=H, eps=cfg.rms_norm_eps, rope=(cos, sin), dtype=dt, kv_len=kv_len, cache=cache)
+        else:
+            self.prefill_layers_per_op(x, layers, B, S, cos, sin, kv_len, cache, dt)
+        h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
+        return h32.view(B, S, D), h16
+
+    def prefill_layers_per_op(self, x, layers, B, S, cos, sin, kv_len, cache, dt):
+        """The decoder-layer loop as one C-ABI call per op — what stllm_llama_layers issues from C.  Kept as the reference the stack
+        entry point is tested against (-m gpu: bit-identical) and as the body the test-only CPU contract backend runs."""
+        cfg = self.config
+        D = cfg.hidden_size
+        H = cfg.num_attention_heads
+        hd = D // H
         for li_, pk in enumerate(layers):
             h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
             if cache is None:
@@ -165,8 +189,7 @@ class LlamaModel(nn.Module):
             h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
             g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
-        h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
-        return h32.view(B, S, D), h16
+        return x
 
     def decode_step(self, x_new, cache):
         """One token per sequence: x_new f32 [B,1,D] (embedding of the token at position cache.len).  Appends its K/V to the

@@ -236,8 +236,8 @@ class STLLMModel(Blip2Base):
             b_i = torch.arange(B).view(B, 1, 1)
             r_i = torch.as_tensor(ridx).view(1, R, 1)
             l_i = torch.arange(Lq).view(1, 1, Lq)
-            idx = ((b_i * T + r_i) * Lq + l_i).reshape(-1).to(torch.int32).to(img_embeds.device)
-            idx_add = (b_i * Lq + l_i).expand(B, R, Lq).reshape(-1).to(torch.int32).to(img_embeds.device)
+            idx = hip.h2d(((b_i * T + r_i) * Lq + l_i).reshape(-1).to(torch.int32), img_embeds.device)
+            idx_add = hip.h2d((b_i * Lq + l_i).expand(B, R, Lq).reshape(-1).to(torch.int32), img_embeds.device)
             out = hip.gather_rows(img_embeds.reshape(-1, D), idx, add=gg, idx_add=idx_add)
             if self._tape is not None:
                 self._tape.update(pool_g16=g16, pool_h=h, pool_idx=idx, pool_idx_add=idx_add)
@@ -254,7 +254,7 @@ class STLLMModel(Blip2Base):
         """rows: list (B) of lists of gather indices (>=0: row of vis_flat; <0: -(token id)-1) — all the same
         length.  One kernel assembles inputs_embeds [B,S,D] from visual tokens + embedding-table rows."""
         B, S = len(rows), len(rows[0])
-        idx = torch.tensor(rows, dtype=torch.int32).reshape(-1).to(vis_flat.device)
+        idx = hip.h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1), vis_flat.device)
         out = hip.gather_rows(vis_flat, idx, src_b=self.embed_tokens.weight)
         if self._tape is not None:
             self._tape.setdefault("gather_idx", []).append(idx)
@@ -376,8 +376,8 @@ class STLLMModel(Blip2Base):
         if mask is not None:
             urows, un_a, _ = self._assemble(L, [list(range(L))] * B, instruction, answers, B)
             un_e = self._gather_tokens(vis_flat, urows)
-            un_a = un_a.to(dev)
-        return inputs_embeds, attention_mask.to(dev), un_e, un_a, targets.to(dev)
+            un_a = hip.with_host(un_a, dev)
+        return inputs_embeds, hip.with_host(attention_mask, dev), un_e, un_a, hip.with_host(targets, dev)
 
     @classmethod
     def from_config(cls, cfg, device=None):
@@ -452,7 +452,7 @@ class STLLMLlamaModel(LlamaModel):
         Lk = sm.mask_img_len
         dev = mask_output.device
         rows = (torch.arange(B).view(B, 1) * S1 + img_start + torch.arange(Lk).view(1, Lk)).reshape(-1)
-        a = hip.gather_rows(mask_output.reshape(B * S1, D), rows.to(torch.int32).to(dev))
+        a = hip.gather_rows(mask_output.reshape(B * S1, D), hip.h2d(rows.to(torch.int32), dev))
         if hasattr(sm, "mvm_decoder"):
             a = sm.mvm_decoder(a)
         un_out = super().forward(inputs_embeds=un_e, attention_mask=un_a, return_dict=True, use_cache=False,
@@ -460,7 +460,7 @@ class STLLMLlamaModel(LlamaModel):
         S2 = un_out.shape[1]
         keep = (~sm.mask.squeeze(1))
         pos = torch.stack([torch.nonzero(keep[b]).flatten() for b in range(B)])  # [B, Lk]
-        idx_b = (torch.arange(B).view(B, 1) * S2 + img_start + pos).reshape(-1).to(torch.int32).to(dev)
+        idx_b = hip.h2d((torch.arange(B).view(B, 1) * S2 + img_start + pos).reshape(-1).to(torch.int32), dev)
         loss_rows = hip.cosine_rows(a, un_out.reshape(B * S2, D), None, idx_b, n_rows=B * Lk)
         return outputs, loss_rows.mean(), labels
 
@@ -513,10 +513,17 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
         logits = self.logits_from(outputs._h16, B, S)
         loss = None
         if labels is not None:  # shifted CE (st_llm.py:125-135)
-            shift = torch.full_like(labels, -100)
-            shift[:, :-1] = labels[:, 1:]
-            rows = hip.cross_entropy_rows(logits.reshape(B * S, -1), shift.reshape(-1).to(torch.int32))
-            loss = rows.sum() / (shift != -100).sum().clamp(min=1)
+            lab_h = getattr(labels, "_stllm_host", None)
+            if lab_h is not None:   # the targets were built on the host (st_llm.py:532-542): shift them there, one asynchronous H2D copy
+                shift_h = torch.full_like(lab_h, -100)
+                shift_h[:, :-1] = lab_h[:, 1:]
+                rows = hip.cross_entropy_rows(logits.reshape(B * S, -1), hip.h2d(shift_h.reshape(-1).to(torch.int32), logits.device))
+                loss = rows.sum() / max(int((shift_h != -100).sum()), 1)
+            else:
+                shift = torch.full_like(labels, -100)
+                shift[:, :-1] = labels[:, 1:]
+                rows = hip.cross_entropy_rows(logits.reshape(B * S, -1), shift.reshape(-1).to(torch.int32))
+                loss = rows.sum() / (shift != -100).sum().clamp(min=1)
         if loss_pretrain is not None:
             loss = loss + loss_pretrain
         hip.gemm_workspace_check(logits.device) if logits.is_cuda else None   # non-blocking (see hip.gemm_workspace_check)

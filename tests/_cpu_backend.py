@@ -349,6 +349,33 @@ def sumsq(x, out=None):
     return out
 
 
+def vit_block_array(blocks):
+    return None
+
+
+def vit_blocks(x, blocks, carr, *, n_seq, seq_len, num_heads, dtype):
+    """stllm_vit_blocks: the block loop, one contract call per op (what the C entry point issues)"""
+    from stllm_amd.models.eva_vit import block_forward
+    for bp in blocks:
+        block_forward(x, bp, n_seq, seq_len, num_heads, dtype)
+    return x
+
+
+def llama_layer_array(layers, cache=None):
+    return None
+
+
+class _LM:   # the bits of LlamaModel that prefill_layers_per_op reads
+    def __init__(self, hidden, n_heads, eps):
+        import types
+        self.config = types.SimpleNamespace(hidden_size=hidden, num_attention_heads=n_heads, rms_norm_eps=eps)
+
+
+def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=None, cache=None):
+    from stllm_amd.models.llama import LlamaModel
+    return LlamaModel.prefill_layers_per_op(_LM(x.shape[1], n_heads, eps), x, layers, B, S, rope[0], rope[1], kv_len, cache, dtype)
+
+
 @contextlib.contextmanager
 def installed():
     """Monkey-patch stllm_amd.hip's compute entry points with the functions above (tests only)."""
@@ -356,7 +383,8 @@ def installed():
     names = ["gemm", "layernorm", "rmsnorm", "attention", "gather_rows", "mean_t", "vit_cls_rows", "cosine_rows",
              "cross_entropy_rows", "cast_rows", "preprocess_frames", "transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu",
              "swiglu_bwd", "rope_bwd", "attention_bwd", "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum",
-             "relu_bwd", "gelu", "gelu_bwd", "scale_rows", "bcast_add_t", "adamw", "sumsq"]
+             "relu_bwd", "gelu", "gelu_bwd", "scale_rows", "bcast_add_t", "adamw", "sumsq", "vit_block_array", "vit_blocks",
+             "llama_layer_array", "llama_layers"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

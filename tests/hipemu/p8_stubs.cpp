@@ -9,3 +9,6 @@ extern "C" int stllm_gemm_plan(int, int, int, int, int, int*) { return STLLM_ERR
 int stllm_gemm_w4_launch_bf16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
 int stllm_gemm_w4_launch_f16(int, int, const sg::GemmParams&, hipStream_t) { return STLLM_ERR_UNSUPPORTED; }
 float stllm_gemm_w4_estimate_us(int, int, int, int, int* shape, int* split) { if (shape) *shape = 44; if (split) *split = 1; return 1.0e30f; }
+// profile.cpp (HIP events) is not part of the emulated library either
+int stllm_prof_begin(const stllm_gemm_args*, void*) { return -1; }
+void stllm_prof_end(int, const stllm_gemm_args*, void*) {}

@@ -231,6 +231,41 @@ def test_config5_minigpt4base_btadapter_vs_oracle():
     assert abs(out.loss.item() - ref["loss"].item()) <= 1e-3
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_stack_entry_points_are_bit_identical_to_the_per_op_path(mode):
+    """stllm_vit_blocks / stllm_llama_layers (one C call per layer stack, csrc/stacks.cpp) issue exactly the launches of the per-op host
+    loops: same kernels, same arguments -> the same bits.  ViT: 3 blocks x 3 frames; Llama: 2 layers, B = 2 right-padded rows (kv_len)
+    and B = 2 into a KV cache (2-level output rows)."""
+    from stllm_amd import runtime
+    from stllm_amd.models import llama as llama_mod
+    from stllm_amd.models.eva_vit import create_eva_vit_g
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    vit = fill(create_eva_vit_g(depth=3, device="cuda"), "visual_encoder.")
+    frames = T("input.frames3", (3, 3, 224, 224)).cuda()
+    lm = fill(STLLMForCausalLM(StllmConfig(num_hidden_layers=2), device="cuda")).model
+    emb = T("input.inputs_embeds", (2, 131, 4096), 0.05).cuda()
+    am = torch.ones(2, 131, dtype=torch.long)
+    am[1, 97:] = 0
+    res = {}
+    old = llama_mod.STACK_ENTRY
+    try:
+        for flag in (False, True):
+            llama_mod.STACK_ENTRY = flag
+            with runtime.use_dtype(mode):
+                f = vit(frames).clone()
+                h_pad, _ = lm.prefill(emb, am.cuda())
+                cache = lm.new_cache(2, 140, "cuda")
+                h_c, _ = lm.prefill(emb, None, cache=cache)
+                res[flag] = (f, h_pad.clone(), h_c.clone(), [c[:, :131].clone() for c in cache.qkv])
+    finally:
+        llama_mod.STACK_ENTRY = old
+    assert torch.equal(res[False][0], res[True][0]), "ViT block stack"
+    assert torch.equal(res[False][1][0], res[True][1][0]) and torch.equal(res[False][1][1, :97], res[True][1][1, :97]), "Llama stack, padded rows"
+    assert torch.equal(res[False][2], res[True][2]), "Llama stack into the KV cache"
+    for a, b in zip(res[False][3], res[True][3]):
+        assert torch.equal(a, b)
+
+
 def test_config4_mvm_forward_t32_vs_oracle():
     """BASELINE configs[3] at its stated T: T = 32 frames, 'all' pooling (L = 1024 visual tokens), injected mask at rate 0.5 (512 kept),
     MVM branch on (st_llm.py:71-91, 480-493): the masked pass prefills S ~ 560 positions, the un-masked pass S ~ 1100 — the longest causal
