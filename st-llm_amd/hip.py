@@ -152,14 +152,65 @@ def _p(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
+class _PinnedRing:
+    """Persistent pinned staging memory for the small host -> device copies of a step (index tables, lengths, labels).  `tensor.pin_memory()`
+    per copy allocates pinned memory through the runtime, which SYNCHRONISES the device: the host then loses its whole lead over the GPU
+    (measured: the first index table of the Q-Former stalled the host until the ViT had finished, and everything after it ran host-bound,
+    profiles/r03_gaps.md).  Slots are reused round-robin; a slot's previous copy is awaited through its event before it is overwritten."""
+    SLOTS, SLOT_BYTES = 128, 1 << 16
+
+    def __init__(self):
+        self.buf = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.i = 0
+
+    def stage(self, t, dev):
+        nbytes = t.numel() * t.element_size()
+        if nbytes > self.SLOT_BYTES or nbytes == 0:
+            return None
+        k, self.i = self.i, (self.i + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        view = self.buf[k * self.SLOT_BYTES: k * self.SLOT_BYTES + nbytes].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        out = view.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.events[k] = ev
+        return out
+
+
+_pinned_ring = None
+
+
 def h2d(t, device):
-    """Host tensor -> device WITHOUT stalling the host: staged through pinned memory and enqueued on the current stream.  A pageable
-    `.to(device)` blocks the host until everything queued before the copy has run — one pipeline bubble (~70 us of idle GPU plus the
-    host's lost lead) per index table; profiles/r03_gaps_before.md counted 8 of them per step."""
+    """Host tensor -> device WITHOUT stalling the host: staged through the persistent pinned ring and enqueued on the current stream.
+    A pageable `.to(device)` blocks the host until everything queued before the copy has run, and so does a fresh `pin_memory()`
+    allocation — one pipeline bubble plus the host's lost lead per index table (profiles/r03_gaps.md)."""
+    global _pinned_ring
     dev = torch.device(device)
     if dev.type != "cuda" or t.is_cuda:
         return t.to(dev)
-    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+    if _pinned_ring is None:
+        _pinned_ring = _PinnedRing()
+    out = _pinned_ring.stage(t.contiguous(), dev)
+    return out if out is not None else t.to(dev)
+
+
+_const_tables = {}
+
+
+def arange_repeat(n_inner, n_outer, device):
+    """int32 [n_outer * n_inner] = (0 .. n_inner-1) repeated n_outer times, resident on the device (a constant table, like the RoPE
+    tables: built once per shape)"""
+    key = (n_inner, n_outer, str(device))
+    t = _const_tables.get(key)
+    if t is None:
+        t = torch.arange(n_inner, dtype=torch.int32).repeat(n_outer).to(device)
+        if len(_const_tables) > 64:
+            _const_tables.clear()
+        _const_tables[key] = t
+    return t
 
 
 def host_mask(t):
@@ -188,6 +239,7 @@ def _req(t, dtype=None, what="tensor"):
 
 _workspaces = {}   # (device index, stream handle) -> workspace
 _ws_streams = {}   # (device index, stream handle) -> the torch stream object the workspace belongs to
+_ws_probe_host = {}   # (device index, stream handle) -> pinned int32[1], allocated once
 _ws_probes = {}    # (device index, stream handle) -> (pinned int32[1], event): the error word as of the previous check
 _ERR_WORD_BYTE = 1000 * 4   # kSkErrWord of csrc/gemm_common.h
 
@@ -281,7 +333,9 @@ def gemm_workspace_check(device=None, wait=False):
                                    "of that launch — and of everything computed from them — are invalid")
             probe = None
         if probe is None:
-            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            host = _ws_probe_host.get(key)
+            if host is None:      # ONE pinned word per workspace for the life of the process: a pin_memory() per check synchronises the device
+                host = _ws_probe_host[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
             with torch.cuda.stream(_ws_streams[key]):   # behind the GEMMs of THAT stream, not of whichever stream is current here
                 host.copy_(ws[_ERR_WORD_BYTE: _ERR_WORD_BYTE + 4].view(torch.int32), non_blocking=True)
                 ev = torch.cuda.Event()

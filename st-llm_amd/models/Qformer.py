@@ -172,7 +172,7 @@ class BertModel(nn.Module):
         P = enc16.shape[0] // n
         emb = self.embeddings
         # ---- embeddings (Qformer.py:78-108): queries get no position embedding --------------------
-        q_idx = hip.h2d(torch.arange(Q, dtype=torch.int32).repeat(n), dev)
+        q_idx = hip.arange_repeat(Q, n, dev)
         q_emb = hip.gather_rows(query_tokens.float().contiguous(), q_idx)
         hq16, hq32 = hip.layernorm(q_emb, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, dtype=dt, want_f32=True)
         Lt, ht32, ht16, kv_len = 0, None, None, None
@@ -180,7 +180,7 @@ class BertModel(nn.Module):
             Lt = input_ids.shape[1]
             ids = input_ids.reshape(-1).to(torch.int64)
             w_idx = hip.h2d((-(ids) - 1).to(torch.int32), dev)
-            p_idx = hip.h2d(torch.arange(Lt, dtype=torch.int32).repeat(n), dev)
+            p_idx = hip.arange_repeat(Lt, n, dev)
             t_emb = hip.gather_rows(emb.word_embeddings.weight, w_idx, src_b=emb.word_embeddings.weight,
                                     add=emb.position_embeddings.weight, idx_add=p_idx)
             ht16, ht32 = hip.layernorm(t_emb, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, dtype=dt, want_f32=True)

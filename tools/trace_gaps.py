@@ -54,6 +54,11 @@ def main():
     for lim in (3, 5, 10, 50):
         big = [g for g in gaps if g > lim]
         print(f"  gaps > {lim:>2} us: {len(big) / n:6.1f} per step, {sum(big) / n / 1e3:.3f} ms per step")
+    order = sorted(range(len(seg)), key=lambda i: -gaps[i])[:12]
+    print("\nlargest gaps (us): previous kernel -> next kernel")
+    for i in order:
+        prev = rows[lo + i - 1][2]
+        print(f"  {gaps[i]:8.1f}  {fam(prev)[:70]} -> {fam(seg[i][2])[:70]}  (launch {i} of the window)")
     print("\n| kernel that follows the gap | launches / step | mean gap us | total gap ms / step | kernel ms / step |")
     print("|---|---|---|---|---|")
     dur = defaultdict(float)
