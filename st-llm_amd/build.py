@@ -29,14 +29,25 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    """Compile every translation unit to an object (in parallel), then link.  Skips when up to date."""
+def build(force=False, verbose=True, trace=False):
+    """Compile every translation unit to an object (in parallel), then link.  Skips when up to date.
+    trace=True: the same library with the in-kernel timeline stamps of gemm_w4.inc compiled in (-DSTLLM_W4_TRACE), written to
+    st-llm_amd/trace/libstllm_hip.so — for tools/gemm_harness only (LD_LIBRARY_PATH=st-llm_amd/trace:...), never loaded by the package."""
+    if trace:
+        return _build_to(os.path.join(HERE, "trace", "libstllm_hip.so"), os.path.join(HERE, "build", "trace"), FLAGS + ["-DSTLLM_W4_TRACE"], verbose)
     stamp = LIB + ".stamp"
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
+    _build_to(LIB, os.path.join(HERE, "build"), FLAGS, verbose)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+def _build_to(LIB, objdir, FLAGS, verbose):
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for s in SOURCES:
@@ -54,10 +65,8 @@ def build(force=False, verbose=True):
             print(out.decode())
         objs.append(obj)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    with open(stamp, "w") as f:
-        f.write(dig)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, trace="--trace" in sys.argv))

@@ -404,12 +404,55 @@ def test_gemm_w4(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
+W4_ODD_SHAPES = [(4112 // 2, 4224, 1408), (576, 1536, 4096), (300, 768, 3072), (97, 384, 6144), (1, 384, 128 * 7), (3072, 2304, 704),
+                 (528, 768, 1408), (596, 384, 256)]   # N % 384 == 0 (stllm_gemm wants N % 128 == 0, the tiles N % 192 == 0); the last two: thin tails past 256-row / 192-row tiles
+
+
+@pytest.mark.parametrize("shape", [43, 33])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", W4_ODD_SHAPES)
+def test_gemm_w4_192_column_tiles(hip, dtype, shape, M, N, K):
+    """round 3: the 256 x 192 and 192 x 192 tiles of the one-wave-per-SIMD kernel (three 32-column fragments per wave: the odd one has
+    its own epilogue path): 16-bit STORE outputs with / without bias, GELU, M tails incl. thin rows, determinism; plans that would
+    need a K-split are refused (the dispatcher then falls back), which the kernel-name assert makes visible."""
+    plan = hip.gemm_w4_plan(M, N, K, 8, shape)
+    hip.set_option("gemm_w4", shape)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda())
+        name = hip.lib().stllm_last_kernel().decode()
+        if plan[2] == 1:
+            assert name.startswith(f"gemm_w4_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},{shape // 10},{shape % 10},STORE,0,"), name
+        check(out, ref, OUT_TOL[dtype], f"w4 {shape} store [{name}]")
+        assert torch.equal(out, hip.gemm(a, w, dtype=dtype, bias=b.cuda())), "not bit-identical across launches"
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], f"w4 {shape} gelu")
+        check(hip.gemm(a, w, dtype=dtype), a64 @ w64.t(), OUT_TOL[dtype], f"w4 {shape} store, no bias")
+        # epilogues the 192-column tiles do not have fall through to the other kernels and stay correct
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True), ref, ACC_TOL[dtype], "forced odd tile, fp32 output -> fallback")
+        assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+    finally:
+        hip.set_option("gemm_w4", -1)
+
+
 def test_gemm_w4_thin_tail_at_vit_fc1_size(hip):
     """ViT fc1 at the benchmarked size on the 256 x 128 tile: 4112 rows = 16 tile rows (768 tiles = three whole rounds) + 16 thin
     rows; GELU 16-bit output; fc2 on the same tile (176 tiles + thin rows on idle workgroups too); the thin rows are checked on
     their own as well."""
     M, N, K = 4112, 6144, 1408
     assert hip.gemm_w4_plan(M, N, K, 2 | 8, 42)[:3] == (3, 0, 1)
+    assert hip.gemm_w4_plan(M, N, K, 2 | 8, 43)[:3] == (2, 0, 1)
+    for dtype in ("bf16", "fp16"):       # round 3: the automatic choice for fc1 is the 256 x 192 tile (two whole rounds + thin rows)
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = (a64.cuda() @ w64.cuda().t() + b.double().cuda()).cpu()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU)
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_w4_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},4,3,STORE,1,"), hip.lib().stllm_last_kernel()
+        check(out, O.gelu(ref), OUT_TOL[dtype], "fc1 gelu (auto: 256 x 192)")
+        check(out[4096:], O.gelu(ref[4096:]), OUT_TOL[dtype], "fc1 gelu, thin rows (auto)")
     hip.set_option("gemm_w4", 42)
     try:
         for dtype in ("bf16", "fp16"):
