@@ -10,6 +10,7 @@ struct StllmOptions {
   int attn_decode_single;  // 1 one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
   int attn_dma;            // STLLM_ATTN_DMA: 1 LDS-DMA attention kernels | 0 register-staged | 2 ...
   int attn_bwd_valu;       // STLLM_ATTN_BWD_VALU: 1 = VALU attention backward also for 16-bit operands
+  int gemm_w4_odd;         // STLLM_GEMM_W4_ODD: 1 (default) the 192-column w4 tiles (256 x 192, 192 x 192) take part in the automatic choice | 0 round-2 choice
   int norm_fast;           // STLLM_NORM_FAST: 1 (default) wide-row norm kernels | 0 the round-1 kernels
 };
 StllmOptions& stllm_options();
