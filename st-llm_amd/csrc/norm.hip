@@ -23,6 +23,21 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // gamma / beta are requested together with the row (round 3): behind the two reductions their L2 round trip was a second, fully exposed
+  // latency in a kernel that is one dependent chain per wave (9.2 -> ~8 us at 4112 x 1408)
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4 gv[NV], bv[RMS ? 1 : NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    const int cc = c < nvec ? c : 0;
+    gv[i] = g4[cc];
+    if constexpr (!RMS) bv[i] = b4[cc];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
     if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     else s += v[i].x + v[i].y + v[i].z + v[i].w;
   }
@@ -44,18 +59,16 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     q = wave_sum(q);
     rstd = rsqrtf(q / (float)D + eps);
   }
-  const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c >= nvec) continue;
-    const float4 g = g4[c];
+    const float4 g = gv[i];
     float4 o;
     o.x = (v[i].x - mean) * rstd * g.x; o.y = (v[i].y - mean) * rstd * g.y;
     o.z = (v[i].z - mean) * rstd * g.z; o.w = (v[i].w - mean) * rstd * g.w;
     if constexpr (!RMS) {
-      const float4 b = b4[c];
+      const float4 b = bv[i];
       o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
     }
     if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
@@ -90,6 +103,19 @@ __global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__
   for (int i = 0; i < NV; ++i) {
     const int c = tid + i * 256;
     v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4 gv[NV], bv[RMS ? 1 : NV];   // requested with the row, consumed behind the reductions (see norm_kernel)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = tid + i * 256;
+    const int cc = c < nvec ? c : 0;
+    gv[i] = g4[cc];
+    if constexpr (!RMS) bv[i] = b4[cc];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
     if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     else s += v[i].x + v[i].y + v[i].z + v[i].w;
   }
@@ -117,18 +143,16 @@ __global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__
     q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     rstd = rsqrtf(q / (float)D + eps);
   }
-  const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = tid + i * 256;
     if (c >= nvec) continue;
-    const float4 g = g4[c];
+    const float4 g = gv[i];
     float4 o;
     o.x = (v[i].x - mean) * rstd * g.x; o.y = (v[i].y - mean) * rstd * g.y;
     o.z = (v[i].z - mean) * rstd * g.z; o.w = (v[i].w - mean) * rstd * g.w;
     if constexpr (!RMS) {
-      const float4 b = b4[c];
+      const float4 b = bv[i];
       o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
     }
     if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
