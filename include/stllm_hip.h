@@ -132,7 +132,7 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
- *                  other kernels' estimates | 32 / 42 / 34 / 44 always, 192 x 128 / 256 x 128 / 192 x 256 / 256 x 256 tile:
+ *                  other kernels' estimates | 32 / 42 / 34 / 43 / 33 always, 192 x 128 / 256 x 128 / 192 x 256 / 256 x 192 / 192 x 192 tile (44 = 256 x 256 was retired in round 3: unsupported, falls back):
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 16) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernels of the decode regime (st-llm_amd/csrc/gemv.hip):
  *                  the 5 beams of demo.py's beam search, small serving batches (5-row step 6.99 -> 4.34 ms on MI355X)

@@ -370,12 +370,12 @@ W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 
              (528, 768, 1408), (596, 384, 256)]   # the last two: a tail of 16 rows past 256-row tiles / 20 rows past 192-row tiles (thin-tail path)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 44, 42])
+@pytest.mark.parametrize("shape", [32, 34, 42])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 def test_gemm_w4(hip, dtype, shape, M, N, K):
     """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128 tiles): whole rounds, remainder-first K-split
-    with the end-of-launch reduction, M / N tails (incl. the thin-tail rows computed outside the tile grid), fp32 / GELU / residual
+    with the end-of-launch reduction, M / N tails (256 x 256 retired in round 3: a forced 44 falls back to the other kernels), (incl. the thin-tail rows computed outside the tile grid), fp32 / GELU / residual
     epilogues, epoch flags, determinism."""
     hip.set_option("gemm_w4", shape)
     try:
@@ -477,7 +477,7 @@ def test_gemm_w4_thin_tail_at_vit_fc1_size(hip):
         hip.set_option("gemm_w4", -1)
 
 
-@pytest.mark.parametrize("shape,n_seq", [(42, 9), (32, 7), (34, 7), (44, 9)])
+@pytest.mark.parametrize("shape,n_seq", [(42, 9), (32, 7), (34, 7)])
 def test_gemm_w4_thin_tail_with_two_level_rows(hip, shape, n_seq):
     """the thin tail rows go through the same 2-level row addressing as the tiles (Q-Former row groups: A rows read from / out rows
     written into a [n, S, C] buffer): n x 32 query rows = one full tile + 32 thin rows, fp32 output and the residual epilogue"""
@@ -503,7 +503,7 @@ def test_gemm_w4_thin_tail_with_two_level_rows(hip, shape, n_seq):
         hip.set_option("gemm_w4", -1)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 44, 42])
+@pytest.mark.parametrize("shape", [32, 34, 42])
 def test_gemm_w4_swiglu_rope_rows(hip, shape):
     from stllm_amd import pack
     dtype = "bf16"
