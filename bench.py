@@ -246,13 +246,20 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
     # ---- N GPUs: frame-parallel, all-gather in the step, clip-parallel prefill ------------------------
     sm.set_frame_parallel(rank, world)
     sm._fp_keep_tokens = True
+    sm._fp_last_tokens = None
     out = None
     for _ in range(1 if dry else 3):
         out = model(samples=samples)
     sync()
     ident, ident_err = None, None
     if rank == 0:
-        got = sm._fp_last_tokens.reshape(ref_tokens.shape)
+        got = sm._fp_last_tokens
+        want = ref_tokens
+        if got.shape[0] != n_frames:     # one clip per rank (N == number of clips): nothing is exchanged, the block is rank 0's own range
+            s0, e0 = ranges[0]
+            want = ref_tokens[s0:e0]
+        got = got.reshape(want.shape)
+        ref_tokens = want
         ident = bool(torch.equal(got, ref_tokens))
         ident_err = float((got - ref_tokens).abs().max().item())
         if not (ident_err <= 1e-3):   # a wrong frame, a wrong rank order or a torn transfer: stop — the timing below would be of a broken path
