@@ -47,7 +47,7 @@ stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes) {
 extern "C" int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden) {
   if (n_seq <= 0 || seq_len <= 0 || dim <= 0 || hidden <= 0) return -1;
   const int64_t M = (int64_t)n_seq * seq_len, e = esize(dtype);
-  return up256(M * dim * e) * 2 + up256(M * 3 * dim * e) + up256(M * hidden * e);
+  return up256(M * dim * e) * 3 + up256(M * 3 * dim * e) + up256(M * hidden * e) + up256(M * (dim / 64 + 1) * 8);
 }
 
 // eva_vit.py:173-180 (Block.forward, gamma_1 / gamma_2 None) x n_blocks on the flat fp32 stream, in place:
@@ -67,17 +67,29 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
   char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* qkv = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
   char* g1 = reinterpret_cast<char*>(c.take((int64_t)M * a->hidden * e));
+  char* xb = reinterpret_cast<char*>(c.take((int64_t)M * D * e));                                 // folded norms: T(x)
+  float* st = reinterpret_cast<float*>(c.take((int64_t)M * (D / 64 + 1) * 8));                    // ... and its row partials [M][D / 64][2]
+  // LayerNorm folded into the GEMMs (stllm_hip.h fold_*): every block must carry the folded weights and both consumers must have a kernel
+  bool fold = a->fold_norms != 0 && n_blocks > 0 && D % 64 == 0 && stllm_gemm_fold_supported(a->dtype, M, D, 3 * D, 0) &&
+              stllm_gemm_fold_supported(a->dtype, M, D, a->hidden, 1);
+  for (int b = 0; b < n_blocks && fold; ++b) fold = blocks[b].wqkv_f && blocks[b].bqkv_f && blocks[b].cs_qkv && blocks[b].wfc1_f && blocks[b].bfc1_f && blocks[b].cs_fc1;
   float scale = 1.0f;
   {   // hd ** -0.5 exactly as the host path computes it (Python float -> float32)
     double s = 1.0;
     s = 1.0 / __builtin_sqrt((double)hd);
     scale = (float)s;
   }
+  if (fold) STACK_TRY(stllm_row_stats(a->dtype, a->x, a->ldx, xb, D, st, M, D, stream));
   for (int b = 0; b < n_blocks; ++b) {
     const stllm_vit_block_weights& w = blocks[b];
-    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
     stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
-    g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
+    if (fold) {   // norm1 inside the qkv GEMM: A = T(x), W = gamma1 (.) wqkv, row statistics from the partials
+      g.epilogue = STLLM_EPI_STORE; g.A = xb; g.lda = D; g.W = w.wqkv_f; g.ldw = w.ld_qkv; g.bias = w.bqkv_f;
+      g.fold_stats_in = st; g.fold_groups = D / 64; g.fold_eps = w.e1; g.fold_colsum = w.cs_qkv;
+    } else {
+      STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
+      g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
+    }
     g.out = qkv; g.ldo = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     const int64_t rs = 3 * D, bs = (int64_t)a->seq_len * rs;
@@ -86,15 +98,22 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wproj; g.ldw = w.ld_proj; g.bias = w.bproj;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
+    if (fold) { g.fold_out_t = xb; g.fold_ldo_t = D; g.fold_stats_out = st; }   // proj also writes T(x) and the row partials norm2 needs
     STACK_TRY(stllm_gemm(&g, stream));
-    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
-    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
+    if (fold) {
+      g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = xb; g.lda = D; g.W = w.wfc1_f; g.ldw = w.ld_fc1; g.bias = w.bfc1_f;
+      g.fold_stats_in = st; g.fold_groups = D / 64; g.fold_eps = w.e2; g.fold_colsum = w.cs_fc1;
+    } else {
+      STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
+      g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
+    }
     g.out = g1; g.ldo = a->hidden; g.M = M; g.N = a->hidden; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = g1; g.lda = a->hidden; g.W = w.wfc2; g.ldw = w.ld_fc2; g.bias = w.bfc2;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->hidden;
+    if (fold && b + 1 < n_blocks) { g.fold_out_t = xb; g.fold_ldo_t = D; g.fold_stats_out = st; }   // (the last block's output is normalised by the caller)
     STACK_TRY(stllm_gemm(&g, stream));
   }
   return STLLM_OK;

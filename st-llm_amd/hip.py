@@ -24,7 +24,8 @@ EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_
            "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_gemm_w4_plan", "stllm_set_option",
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
            "stllm_attention_decode", "stllm_gemm_profile", "stllm_gemm_profile_count", "stllm_gemm_profile_read",
-           "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers"]
+           "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers",
+           "stllm_gemm_fold_supported", "stllm_row_stats"]
 
 
 def torch_dtype(d):
@@ -45,7 +46,9 @@ class GemmArgs(ctypes.Structure):
                 ("a_rows_per_batch", c_int), ("a_batch_stride", c_int64),
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
-                ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float)]
+                ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float),
+                ("fold_out_t", c_void_p), ("fold_ldo_t", c_int64), ("fold_stats_out", c_void_p),
+                ("fold_stats_in", c_void_p), ("fold_groups", c_int), ("fold_eps", ctypes.c_float), ("fold_colsum", c_void_p)]
 
 
 class VitBlockWeights(ctypes.Structure):
@@ -54,13 +57,15 @@ class VitBlockWeights(ctypes.Structure):
                 ("wproj", c_void_p), ("ld_proj", c_int64), ("bproj", c_void_p),
                 ("n2w", c_void_p), ("n2b", c_void_p), ("e2", c_float),
                 ("wfc1", c_void_p), ("ld_fc1", c_int64), ("bfc1", c_void_p),
-                ("wfc2", c_void_p), ("ld_fc2", c_int64), ("bfc2", c_void_p)]
+                ("wfc2", c_void_p), ("ld_fc2", c_int64), ("bfc2", c_void_p),
+                ("wqkv_f", c_void_p), ("bqkv_f", c_void_p), ("cs_qkv", c_void_p),
+                ("wfc1_f", c_void_p), ("bfc1_f", c_void_p), ("cs_fc1", c_void_p)]
 
 
 class VitBlocksArgs(ctypes.Structure):
     _fields_ = [("dtype", c_int), ("n_seq", c_int), ("seq_len", c_int), ("num_heads", c_int), ("dim", c_int), ("hidden", c_int),
                 ("x", c_void_p), ("ldx", c_int64), ("scratch", c_void_p), ("scratch_bytes", c_int64),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("fold_norms", c_int)]
 
 
 class LlamaLayerWeights(ctypes.Structure):
@@ -76,7 +81,7 @@ class LlamaLayersArgs(ctypes.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")
+LIB_PATH = os.environ.get("STLLM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")   # STLLM_LIB: the trace build (tools only)
 _lib = None
 
 
@@ -119,6 +124,8 @@ def _bind(L, strict=True):
     B("stllm_gemm_profile", [c_int, c_char_p])
     B("stllm_gemm_profile_count", [])
     B("stllm_gemm_profile_read", [c_int, c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)])
+    B("stllm_gemm_fold_supported", [c_int] * 5)
+    B("stllm_row_stats", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p])
     B("stllm_vit_blocks_scratch_bytes", [c_int] * 5, c_int64)
     B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
     B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
@@ -390,7 +397,7 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None, a_norm=None):
+         a_rows=None, o_rows=None, a_norm=None, fold_out=None, fold_in=None):
     """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
     a_norm=(x, gamma, eps) with a=None (decode regime, M <= 8, 16-bit dtypes): the A operand is RMSNorm(x) * gamma of the fp32
     rows x [M,K], computed inside the kernel (stllm_hip.h: a_norm_*)."""
@@ -445,10 +452,40 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         args.o_rows_per_batch, args.o_batch_stride = o_rows
     args.out, args.ldo = _p(out), out.stride(-2)
     args.M, args.N, args.K = M, N, K
+    if fold_out is not None:   # producer half of the folded LayerNorm: (out_t [M, N] compute dtype, stats f32 [M, N / 64, 2])
+        ot, st = fold_out
+        _req(ot, td, "fold out_t"); _req(st, torch.float32, "fold stats")
+        args.fold_out_t, args.fold_ldo_t, args.fold_stats_out = _p(ot), ot.stride(-2), _p(st)
+    if fold_in is not None:    # consumer half: (stats f32 [M, K / 64, 2], eps, colsum f32 [N]); w = gamma (.) W, bias = W beta + b
+        st, eps, cs = fold_in
+        _req(st, torch.float32, "fold stats"); _req(cs, torch.float32, "fold colsum")
+        args.fold_stats_in, args.fold_groups, args.fold_eps, args.fold_colsum = _p(st), K // 64, float(eps), _p(cs)
     ws = gemm_workspace(w.device)
     args.workspace, args.workspace_bytes = _p(ws), ws.numel()
     _check(lib().stllm_gemm(ctypes.byref(args), _stream()), "stllm_gemm")
     return out
+
+
+# 1: stllm_vit_blocks runs the ViT's LayerNorms FOLDED into the qkv / fc1 GEMMs (stllm_hip.h fold_*).  Built, parity-green and OFF by default:
+# on MI355X the folded step measures +0.3 ms (the two consumer epilogues cost +6-7 us per tile, the producers +3.8 us per launch, against
+# 23 us of LayerNorm kernels + boundaries saved per layer; profiles/r03_ln_fold.md)
+LN_FOLD = os.environ.get("STLLM_LN_FOLD", "0") == "1"
+
+
+def gemm_fold_supported(dtype, M, D, n_out, gelu=False):
+    return bool(lib().stllm_gemm_fold_supported(dtype_code(torch_dtype(dtype)), M, D, n_out, int(gelu)))
+
+
+def row_stats(x, dtype):
+    """x f32 [M, D] -> (T(x) [M, D], partial (sum, sum of squares) per 64-column group f32 [M, D / 64, 2]) — the producer half of the folded
+    LayerNorm for a stream no GEMM has written yet (stllm_hip.h: stllm_row_stats)"""
+    _req(x, torch.float32, "x")
+    td = torch_dtype(dtype)
+    M, D = x.shape
+    out_t = torch.empty((M, D), device=x.device, dtype=td)
+    stats = torch.empty((M, D // 64, 2), device=x.device, dtype=torch.float32)
+    _check(lib().stllm_row_stats(dtype_code(td), _p(x), x.stride(0), _p(out_t), out_t.stride(0), _p(stats), M, D, _stream()), "stllm_row_stats")
+    return out_t, stats
 
 
 def vit_block_array(blocks):
@@ -462,6 +499,9 @@ def vit_block_array(blocks):
         w.n2w, w.n2b, w.e2 = pk["n2w"].data_ptr(), pk["n2b"].data_ptr(), float(pk["e2"])
         w.wfc1, w.ld_fc1, w.bfc1 = pk["wfc1"].data_ptr(), pk["wfc1"].stride(0), pk["bfc1"].data_ptr()
         w.wfc2, w.ld_fc2, w.bfc2 = pk["wfc2"].data_ptr(), pk["wfc2"].stride(0), pk["bfc2"].data_ptr()
+        if "wqkv_f" in pk:   # LayerNorms folded into qkv / fc1 (pack.fold_layernorm): 16-bit dtypes
+            w.wqkv_f, w.bqkv_f, w.cs_qkv = pk["wqkv_f"].data_ptr(), pk["bqkv_f"].data_ptr(), pk["cs_qkv"].data_ptr()
+            w.wfc1_f, w.bfc1_f, w.cs_fc1 = pk["wfc1_f"].data_ptr(), pk["bfc1_f"].data_ptr(), pk["cs_fc1"].data_ptr()
     return arr
 
 
@@ -476,7 +516,7 @@ def vit_blocks(x, blocks, carr, *, n_seq, seq_len, num_heads, dtype):
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
     ws = gemm_workspace(x.device)
     a = VitBlocksArgs(dtype_code(td), n_seq, seq_len, num_heads, dim, hidden, x.data_ptr(), x.stride(0), scratch.data_ptr(), need,
-                      ws.data_ptr(), ws.numel())
+                      ws.data_ptr(), ws.numel(), int(LN_FOLD))
     _check(L.stllm_vit_blocks(ctypes.byref(a), carr, len(blocks), _stream()), "stllm_vit_blocks")
     return x
 

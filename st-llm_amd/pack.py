@@ -28,6 +28,18 @@ def linear(w, dtype):
     return _cast(w, dtype)
 
 
+def fold_layernorm(w, bias, gamma, beta, dtype):
+    """LayerNorm folded into the Linear that follows it (stllm_hip.h fold_*): y = LN(x) W^T + b = rstd (x - mean) (gamma (.) W)^T + (W beta + b).
+    Returns (W' = gamma (.) W in `dtype`, bias' = W beta + b in fp32, colsum[n] = sum_k W'[n, k] of the ROUNDED W' in fp32 — the term the
+    consumer epilogue multiplies with -rstd * mean must match what the MFMAs actually summed)."""
+    wf = w.detach().float()
+    wq = (wf * gamma.detach().float()[None, :]).to(torch_dtype(dtype)).contiguous()
+    b = wf @ beta.detach().float()
+    if bias is not None:
+        b = b + bias.detach().float()
+    return wq, b.contiguous(), wq.float().sum(dim=1).contiguous()
+
+
 def f32(b):
     return None if b is None else b.detach().float().contiguous()
 

@@ -437,6 +437,61 @@ def test_gemm_w4_192_column_tiles(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,D,Nq,Nf", [(4112, 1408, 4224, 6144), (32 * 257, 1408, 4224, 6144)])
+def test_gemm_layernorm_fold(hip, dtype, M, D, Nq, Nf):
+    """round 3: LayerNorm folded into the two GEMMs around it (stllm_gemm_args fold_*; eva_vit.py:173-180).  PRODUCER (RESID): besides the fp32
+    stream it writes T(x) and per-row partial (sum, sum of squares) per 64-column group; CONSUMER (STORE, +- GELU): A = T(x), W = gamma (.) W,
+    epilogue rstd * (acc - mean * colsum) + bias' == LayerNorm(x) W^T + b.  Also stllm_row_stats (the stream's first statistics) and thin
+    tail rows (4112 = 16 x 256 + 16 on the 256 x 192 consumer tile).  Small problems (plans with a K-split) are not supported: the query says
+    so and stllm_gemm refuses instead of falling back silently."""
+    from stllm_amd import pack
+    td = hip.torch_dtype(dtype)
+    assert hip.gemm_fold_supported(dtype, M, D, Nq) and hip.gemm_fold_supported(dtype, M, D, Nf, gelu=True)
+    assert not hip.gemm_fold_supported(dtype, 2 * 257, D, Nq) and not hip.gemm_fold_supported("fp32", M, D, Nq)
+    with pytest.raises(RuntimeError, match="fold"):
+        xs_, st_ = hip.row_stats(torch.zeros(514, D, device="cuda"), dtype)
+        hip.gemm(xs_, torch.zeros(Nq, D, device="cuda", dtype=td), dtype=dtype, fold_in=(st_, 1e-6, torch.zeros(Nq, device="cuda")))
+    a, a64 = rnd("a", (M, D), dtype, 0.5)
+    wp, wp64 = rnd("wp", (D, D), dtype, 0.05)
+    bp = T("bp", (D,), 0.5)
+    x0 = T("x", (M, D), 2.0) + 0.3          # rows with a non-zero mean
+    x = x0.cuda()
+    xb = torch.empty((M, D), device="cuda", dtype=td)
+    st = torch.empty((M, D // 64, 2), device="cuda", dtype=torch.float32)
+    hip.gemm(a, wp, dtype=dtype, epilogue=hip.EPI_RESID, bias=bp.cuda(), resid=x, fold_out=(xb, st))
+    assert ",FOLD1>" in hip.lib().stllm_last_kernel().decode()
+    want_x = x0.double() + a64 @ wp64.t() + bp.double()
+    check(x, want_x, ACC_TOL[dtype], "producer: stream")
+    assert torch.equal(xb.cpu(), x.cpu().to(td)), "producer: compute-dtype copy == cast of the stream it wrote"
+    xs = x.cpu().double().view(M, D // 64, 64)
+    assert (st.cpu()[..., 0].double() - xs.sum(-1)).abs().max() <= 2e-3 and (st.cpu()[..., 1].double() - (xs * xs).sum(-1)).abs().max() <= 2e-1
+    xb2, st2 = hip.row_stats(x, dtype)        # the same statistics from the stand-alone kernel
+    assert torch.equal(xb2, xb) and (st2 - st).abs().max().item() <= 1e-2
+    # ---- consumers ------------------------------------------------------------------------------------------------------------------
+    g, b = T("ln_g", (D,), 0.3) + 1.0, T("ln_b", (D,), 0.3)
+    xd = x.cpu().double()
+    ln = (xd - xd.mean(-1, keepdim=True)) / torch.sqrt(xd.var(-1, unbiased=False, keepdim=True) + 1e-6) * g.double() + b.double()
+    for N, gelu in ((Nq, False), (Nf, True)):
+        w = T(f"w{N}", (N, D), 0.05)
+        bias = T(f"b{N}", (N,), 0.5)
+        wf, bf, cs = pack.fold_layernorm(w.cuda(), bias.cuda(), g.cuda(), b.cuda(), dtype)
+        out = hip.gemm(xb, wf, dtype=dtype, bias=bf, act=hip.ACT_GELU if gelu else hip.ACT_NONE, fold_in=(st, 1e-6, cs))
+        name = hip.lib().stllm_last_kernel().decode()
+        assert ",FOLD2>" in name, name
+        ref = ln @ w.double().t() + bias.double()
+        # tolerance: the A operand is rounded BEFORE the normalisation (|x| ~ 2.5 here, vs |LN(x)| ~ 1), W' = gamma (.) W once more
+        check(out, O.gelu(ref) if gelu else ref, 3 * OUT_TOL[dtype], f"consumer N={N} gelu={gelu} [{name}]")
+        h = hip.layernorm(x, g.cuda(), b.cuda(), 1e-6, dtype=dtype)[0]   # against the un-folded product path: same size of error
+        plain = hip.gemm(h, w.cuda().to(td), dtype=dtype, bias=bias.cuda(), act=hip.ACT_GELU if gelu else hip.ACT_NONE)
+        e_fold = (out.double().cpu() - (O.gelu(ref) if gelu else ref)).abs().max().item()
+        e_plain = (plain.double().cpu() - (O.gelu(ref) if gelu else ref)).abs().max().item()
+        print(f"\n[fold {dtype} M={M} N={N}] max-abs err folded {e_fold:.3e} vs LayerNorm kernel + GEMM {e_plain:.3e}")
+        assert e_fold <= 3.0 * e_plain + 1e-3
+        assert torch.equal(out, hip.gemm(xb, wf, dtype=dtype, bias=bf, act=hip.ACT_GELU if gelu else hip.ACT_NONE, fold_in=(st, 1e-6, cs)))
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+
+
 def test_gemm_w4_thin_tail_at_vit_fc1_size(hip):
     """ViT fc1 at the benchmarked size on the 256 x 128 tile: 4112 rows = 16 tile rows (768 tiles = three whole rounds) + 16 thin
     rows; GELU 16-bit output; fc2 on the same tile (176 tiles + thin rows on idle workgroups too); the thin rows are checked on

@@ -266,6 +266,32 @@ def test_stack_entry_points_are_bit_identical_to_the_per_op_path(mode):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode,tol", [("fp16", 1e-2), ("bf16", 5e-2)])
+def test_vit_layernorm_fold_vs_kernels_vs_oracle(mode, tol):
+    """stllm_vit_blocks with the LayerNorms folded into qkv / fc1 (opt-in: STLLM_LN_FOLD=1) against the same stack with the norms as
+    kernels and against the oracle: 3 blocks x 16 frames (M = 4112: the benchmarked row count, thin tail rows included)."""
+    from stllm_amd import hip, runtime
+    from stllm_amd.models.eva_vit import create_eva_vit_g
+    vit = fill(create_eva_vit_g(depth=3, device="cuda"), "visual_encoder.")
+    frames = T("input.frames16", (16, 3, 224, 224)).cuda()
+    want = O.vit_forward(frames.cpu(), sd_from(shapes.vit_shapes(3)), "visual_encoder.")
+    res = {}
+    old = hip.LN_FOLD
+    try:
+        for flag in (True, False):
+            hip.LN_FOLD = flag
+            with runtime.use_dtype(mode):
+                res[flag] = vit(frames).float().cpu()
+            res[flag, "k"] = hip.lib().stllm_last_kernel().decode()
+    finally:
+        hip.LN_FOLD = old
+    e_fold, e_plain = rel_err(res[True], want), rel_err(res[False], want)
+    print(f"\n[vit fold {mode}] rel err folded {e_fold:.3e}, norms as kernels {e_plain:.3e}; fold vs kernels {rel_err(res[True], res[False]):.3e}")
+    assert e_fold <= tol and e_plain <= tol
+    assert e_fold <= 2.0 * e_plain + 1e-4
+    assert not torch.equal(res[True], res[False]), "the folded path did not run (identical bits)"
+
+
 def test_config4_mvm_forward_t32_vs_oracle():
     """BASELINE configs[3] at its stated T: T = 32 frames, 'all' pooling (L = 1024 visual tokens), injected mask at rate 0.5 (512 kept),
     MVM branch on (st_llm.py:71-91, 480-493): the masked pass prefills S ~ 560 positions, the un-masked pass S ~ 1100 — the longest causal
