@@ -33,6 +33,9 @@ def build(force=False, verbose=True, trace=False):
     """Compile every translation unit to an object (in parallel), then link.  Skips when up to date.
     trace=True: the same library with the in-kernel timeline stamps of gemm_w4.inc compiled in (-DSTLLM_W4_TRACE), written to
     st-llm_amd/trace/libstllm_hip.so — for tools/gemm_harness only (LD_LIBRARY_PATH=st-llm_amd/trace:...), never loaded by the package."""
+    if trace and trace is not True:   # "--trace-x N": a trace build with a part of the w4 epilogue cut out (timeline experiments; results are garbage)
+        return _build_to(os.path.join(HERE, f"trace_x{int(trace)}", "libstllm_hip.so"), os.path.join(HERE, "build", f"trace_x{int(trace)}"),
+                         FLAGS + ["-DSTLLM_W4_TRACE", f"-DSTLLM_W4_EXPERIMENT={int(trace)}"], verbose)
     if trace:
         return _build_to(os.path.join(HERE, "trace", "libstllm_hip.so"), os.path.join(HERE, "build", "trace"), FLAGS + ["-DSTLLM_W4_TRACE"], verbose)
     stamp = LIB + ".stamp"
@@ -69,4 +72,7 @@ def _build_to(LIB, objdir, FLAGS, verbose):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, trace="--trace" in sys.argv))
+    tr = "--trace" in sys.argv
+    if "--trace-x" in sys.argv:
+        tr = int(sys.argv[sys.argv.index("--trace-x") + 1])
+    print(build(force="--force" in sys.argv, trace=tr))

@@ -198,53 +198,69 @@ __device__ __forceinline__ float erf_as(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
-// GELU for 16-bit OUTPUTS of the phased GEMM epilogue: Phi(x) = 0.5 + x * P(x^2) on |x| <= 4.3 with a degree-8 polynomial
-// fitted to 0.5*erf(x/sqrt2)/x: |Phi error| <= 1.3e-5, |GELU error| <= 5.5e-5 absolute (below the fp16 / bf16 rounding of any
-// result of magnitude >= 0.1; in the far negative tail, where GELU itself is < 1e-3, the relative error reaches 1e-2), exact 0
-// below -4.3.
-// 14 full-rate VALU ops instead of ~12 + two quarter-rate transcendentals: the GELU pass of one 192x256 tile drops from
-// ~7 us to ~3.5 us of pure VALU time that nothing else can hide (profiles/r01_gemm_p8.md).
+// GELU for 16-bit OUTPUTS of the GEMM epilogues: Phi(x) = 0.5 + xc * P(xc^2), xc = clamp(x, -X0, X0), P of degree 8 — a minimax fit of
+// 0.5 * erf(x / sqrt2) / x on |x| <= 4.3 under the END-POINT CONSTRAINT X0 * P(X0^2) = 0.5 (tools/fit_gelu_poly.py), so that the clamp alone
+// gives both tails: Phi(-X0) = 3.7e-10 and Phi(X0) = 1 in float32 at X0 = 4.299341 (no compare + select per element as in round 2).
+// |GELU error| <= 5.0e-5 absolute (below the fp16 / bf16 rounding of any result of magnitude >= 0.1; in the far negative tail, where GELU
+// itself is < 1e-3, the relative error reaches 1e-2).  13 packed VALU ops per PAIR of values (round 2: 17) against ~12 + two quarter-rate
+// transcendentals per value for the erf form.
+#define STLLM_GELU_X0 4.299341f
+#define STLLM_GELU_C8 4.2724678e-11f
+#define STLLM_GELU_C7 -4.30107e-09f
+#define STLLM_GELU_C6 1.9167794e-07f
+#define STLLM_GELU_C5 -5.0263316e-06f
+#define STLLM_GELU_C4 8.7241504e-05f
+#define STLLM_GELU_C3 -0.0010712498f
+#define STLLM_GELU_C2 0.009688736f
+#define STLLM_GELU_C1 -0.066122375f
+#define STLLM_GELU_C0 0.39874327f
 __device__ __forceinline__ float gelu_poly16(float x) {
-  const float xc = __builtin_amdgcn_fmed3f(x, -4.3f, 4.3f);
+  const float xc = __builtin_amdgcn_fmed3f(x, -STLLM_GELU_X0, STLLM_GELU_X0);
   const float t = xc * xc;
-  float p = 5.1581142135326274e-11f;
-  p = fmaf(p, t, -5.033940375653856e-09f);
-  p = fmaf(p, t, 2.1685210072064365e-07f);
-  p = fmaf(p, t, -5.490918738360051e-06f);
-  p = fmaf(p, t, 9.222461812896654e-05f);
-  p = fmaf(p, t, -0.00110264727845788f);
-  p = fmaf(p, t, 0.009800615720450878f);
-  p = fmaf(p, t, -0.06632684171199799f);
-  p = fmaf(p, t, 0.3988965153694153f);
-  float phi = fmaf(xc, p, 0.5f);
-  phi = x < -4.3f ? 0.0f : phi;
-  return x * phi;
+  float p = fmaf(STLLM_GELU_C8, t, STLLM_GELU_C7);
+  p = fmaf(p, t, STLLM_GELU_C6);
+  p = fmaf(p, t, STLLM_GELU_C5);
+  p = fmaf(p, t, STLLM_GELU_C4);
+  p = fmaf(p, t, STLLM_GELU_C3);
+  p = fmaf(p, t, STLLM_GELU_C2);
+  p = fmaf(p, t, STLLM_GELU_C1);
+  p = fmaf(p, t, STLLM_GELU_C0);
+  return x * fmaf(xc, p, 0.5f);
 }
-// two values at once on the packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per instruction): 17
-// instructions per pair instead of 28; bit-identical to gelu_poly16 on each element
+// NP pairs of values at once on the packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32), the NP polynomial chains INTERLEAVED step by step:
+// a single chain is a string of dependent packed ops, each waiting out its predecessor's latency (+ one hazard s_nop) — with one wave per
+// SIMD nothing else fills those slots and the GELU of a 256 x 192 tile cost 12.6 k cycles instead of ~6 k (profiles/r03_w4_epilogue.md).
+// Bit-identical to gelu_poly16 on each element.
 typedef __attribute__((ext_vector_type(2))) float stllm_f32x2;
+template <int NP>
+__device__ __forceinline__ void gelu_poly16_xn(stllm_f32x2 (&v)[NP]) {
+  auto c = [](float k) { stllm_f32x2 r = {k, k}; return r; };
+  stllm_f32x2 xc[NP], t[NP], q[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    xc[k][0] = __builtin_amdgcn_fmed3f(v[k][0], -STLLM_GELU_X0, STLLM_GELU_X0);
+    xc[k][1] = __builtin_amdgcn_fmed3f(v[k][1], -STLLM_GELU_X0, STLLM_GELU_X0);
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) t[k] = xc[k] * xc[k];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma(c(STLLM_GELU_C8), t[k], c(STLLM_GELU_C7));
+  constexpr float kC[7] = {STLLM_GELU_C6, STLLM_GELU_C5, STLLM_GELU_C4, STLLM_GELU_C3, STLLM_GELU_C2, STLLM_GELU_C1, STLLM_GELU_C0};
+#pragma unroll
+  for (int d = 0; d < 7; ++d) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma(q[k], t[k], c(kC[d]));
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) q[k] = __builtin_elementwise_fma(xc[k], q[k], c(0.5f));
+#pragma unroll
+  for (int k = 0; k < NP; ++k) v[k] = v[k] * q[k];
+}
 __device__ __forceinline__ void gelu_poly16_x2(float& x0, float& x1) {
-  const stllm_f32x2 x = {x0, x1};
-  stllm_f32x2 xc;
-  xc[0] = __builtin_amdgcn_fmed3f(x0, -4.3f, 4.3f);
-  xc[1] = __builtin_amdgcn_fmed3f(x1, -4.3f, 4.3f);
-  const stllm_f32x2 t = xc * xc;
-  auto c = [](float v) { stllm_f32x2 r = {v, v}; return r; };
-  stllm_f32x2 p = c(5.1581142135326274e-11f);
-  p = __builtin_elementwise_fma(p, t, c(-5.033940375653856e-09f));
-  p = __builtin_elementwise_fma(p, t, c(2.1685210072064365e-07f));
-  p = __builtin_elementwise_fma(p, t, c(-5.490918738360051e-06f));
-  p = __builtin_elementwise_fma(p, t, c(9.222461812896654e-05f));
-  p = __builtin_elementwise_fma(p, t, c(-0.00110264727845788f));
-  p = __builtin_elementwise_fma(p, t, c(0.009800615720450878f));
-  p = __builtin_elementwise_fma(p, t, c(-0.06632684171199799f));
-  p = __builtin_elementwise_fma(p, t, c(0.3988965153694153f));
-  stllm_f32x2 phi = __builtin_elementwise_fma(xc, p, c(0.5f));
-  phi[0] = x0 < -4.3f ? 0.0f : phi[0];
-  phi[1] = x1 < -4.3f ? 0.0f : phi[1];
-  const stllm_f32x2 y = x * phi;
-  x0 = y[0];
-  x1 = y[1];
+  stllm_f32x2 v[1] = {{x0, x1}};
+  gelu_poly16_xn<1>(v);
+  x0 = v[0][0];
+  x1 = v[0][1];
 }
 __device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 

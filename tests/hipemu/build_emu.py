@@ -16,7 +16,7 @@ DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libstllm_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "p8_stubs.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp", "stacks.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "p8_stubs.cpp")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
     tus = []
@@ -50,7 +50,7 @@ def build(force=False):
         tus.append(tu)
     flags = ["-x", "c++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-pthread", "-Wno-unused-value", "-Wno-comment", "-Wno-psabi",
              "-I", HERE, "-I", OUT, "-I", CSRC]
-    units = tus + [os.path.join(HERE, "p8_stubs.cpp"), os.path.join(CSRC, "error.cpp")]
+    units = tus + [os.path.join(HERE, "p8_stubs.cpp"), os.path.join(CSRC, "error.cpp"), os.path.join(CSRC, "stacks.cpp")]   # stacks.cpp: host code over the C ABI
 
     def compile_one(src):
         obj = os.path.join(OUT, os.path.basename(src) + ".o")

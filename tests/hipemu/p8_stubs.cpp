@@ -13,3 +13,4 @@ float stllm_gemm_w4_estimate_us(int, int, int, int, int* shape, int* split) { if
 int stllm_prof_begin(const stllm_gemm_args*, void*) { return -1; }
 void stllm_prof_end(int, const stllm_gemm_args*, void*) {}
 int stllm_gemm_w4_fold_consumer_shape(int, int, int, int) { return 0; }
+extern "C" int stllm_gemm_w4_plan(int, int, int, int, int, int*) { return STLLM_ERR_UNSUPPORTED; }

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Minimax fit of the GELU used by the 16-bit GEMM epilogues (csrc/common.h gelu_poly16):
+    GELU(x) = x * Phi(x),  Phi(x) ~ 0.5 + xc * P(xc^2),  xc = clamp(x, -X0, X0),  P of degree DEG in t = x^2
+with the END-POINT CONSTRAINT X0 * P(X0^2) = 0.5, so that Phi(-X0) = 0 and Phi(X0) = 1 exactly: the clamp alone gives the two tails
+(no compare + select per element).  Linear program over a dense grid (scipy HiGHS); prints the coefficients in Horner order and the
+maximum absolute GELU error, evaluated in float32 Horner arithmetic as the kernel does.
+    python tools/fit_gelu_poly.py [X0=4.3] [DEG=8]"""
+import sys
+
+import numpy as np
+from scipy.optimize import linprog
+from scipy.special import erf
+
+X0 = float(sys.argv[1]) if len(sys.argv) > 1 else 4.3
+DEG = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+
+x = np.cos(np.linspace(0, np.pi / 2, 4001))[::-1] * X0            # Chebyshev-spaced grid on [0, X0]
+u = (x / X0) ** 2                                                    # scaled variable in [0, 1]
+phi_half = 0.5 * erf(x / np.sqrt(2.0))                               # Phi(x) - 0.5
+# error of GELU: x * (x * P(x^2) - (Phi - 0.5)), P in the Chebyshev basis of (2u - 1) for conditioning
+V = np.polynomial.chebyshev.chebvander(2 * u - 1, DEG)               # [n, DEG + 1]
+A = (x * x)[:, None] * V
+b = x * phi_half
+n = DEG + 1
+# variables: c[0..DEG], eps
+c_obj = np.zeros(n + 1); c_obj[-1] = 1.0
+A_ub = np.block([[A, -np.ones((len(x), 1))], [-A, -np.ones((len(x), 1))]])
+b_ub = np.concatenate([b, -b])
+A_eq = np.concatenate([X0 * np.polynomial.chebyshev.chebvander(np.array([1.0]), DEG)[0], [0.0]])[None, :]
+b_eq = np.array([0.5])
+r = linprog(c_obj, A_ub=A_ub, b_ub=b_ub, A_eq=A_eq, b_eq=b_eq, bounds=[(None, None)] * n + [(0, None)], method="highs")
+assert r.success, r.message
+cheb = r.x[:n]
+# Chebyshev in (2 t / X0^2 - 1)  ->  monomial in t
+pu = np.polynomial.chebyshev.cheb2poly(cheb)                         # monomial in w = 2u - 1
+pw = np.polynomial.Polynomial(pu)
+pt = pw(np.polynomial.Polynomial([-1.0, 2.0 / (X0 * X0)]))           # substitute w = -1 + 2 t / X0^2
+coef = pt.coef                                                       # c0 + c1 t + ...
+print(f"X0 = {X0}, degree {DEG}: LP minimax |GELU error| = {r.x[-1]:.3e}")
+print("Horner order (highest power first):")
+for c in coef[::-1]:
+    print(f"  {np.float32(c)!r:>28}   {c:.17e}")
+
+# float32 evaluation as the kernel runs it
+xs = np.linspace(-8, 8, 1600001).astype(np.float32)
+xc = np.clip(xs, -np.float32(X0), np.float32(X0))
+t = xc * xc
+p = np.full_like(xs, np.float32(coef[-1]))
+for c in coef[-2::-1]:
+    p = (p.astype(np.float64) * t + np.float32(c)).astype(np.float32)   # fma: one rounding
+phi = (xc.astype(np.float64) * p + 0.5).astype(np.float32)
+y = (xs * phi).astype(np.float32)
+ref = xs.astype(np.float64) * 0.5 * (1.0 + erf(xs.astype(np.float64) / np.sqrt(2.0)))
+err = np.abs(y - ref)
+i = int(err.argmax())
+print(f"float32 Horner: max |GELU error| = {err.max():.3e} at x = {xs[i]:.4f};  phi(-X0) = {phi[0]!r}, phi(X0) = {phi[-1]!r}")
+for lo, hi in ((-8, -4.3), (-4.3, -2), (-2, 2), (2, 4.3), (4.3, 8)):
+    m = (xs >= lo) & (xs <= hi)
+    print(f"  x in [{lo}, {hi}]: max abs err {err[m].max():.3e}")
+
+# The float32 coefficients miss the end-point constraint by ~1e-6: move the CLAMP to the float32 xc where the float32 Phi(-xc) is the
+# smallest non-negative value (the fit stays valid below X0), so that far tails give x * (almost 0) and x * (almost 1)
+def phi32(xv):
+    xv = np.float32(xv)
+    tt = np.float32(xv * xv)
+    pp = np.float32(coef[-1])
+    for c in coef[-2::-1]:
+        pp = np.float32(np.float64(pp) * np.float64(tt) + np.float64(np.float32(c)))
+    return np.float32(np.float64(xv) * np.float64(pp) + 0.5)
+lo, hi = np.float32(X0 - 0.5), np.float32(X0)
+cands = []
+xv = lo
+while xv <= hi:
+    cands.append(xv)
+    xv = np.nextafter(xv, np.float32(np.inf), dtype=np.float32)
+    if len(cands) > 5_000_000:
+        break
+cands = np.array(cands, dtype=np.float32)
+# vectorised float32 phi(-x)
+tt = cands * cands
+pp = np.full_like(cands, np.float32(coef[-1]))
+for c in coef[-2::-1]:
+    pp = (pp.astype(np.float64) * tt + np.float32(c)).astype(np.float32)
+ph = ((-cands).astype(np.float64) * pp + 0.5).astype(np.float32)
+ok = ph >= 0
+best = int(np.where(ok, ph, np.float32(1.0)).argmin())
+print(f"clamp at xc = {cands[best]!r}: float32 Phi(-xc) = {ph[best]!r}, Phi(xc) = {phi32(cands[best])!r}")
+XC = cands[best]
+xs = np.linspace(-12, 12, 2400001).astype(np.float32)
+xc = np.clip(xs, -XC, XC)
+t = xc * xc
+p = np.full_like(xs, np.float32(coef[-1]))
+for c in coef[-2::-1]:
+    p = (p.astype(np.float64) * t + np.float32(c)).astype(np.float32)
+phi = (xc.astype(np.float64) * p + 0.5).astype(np.float32)
+y = (xs * phi).astype(np.float32)
+ref = xs.astype(np.float64) * 0.5 * (1.0 + erf(xs.astype(np.float64) / np.sqrt(2.0)))
+err = np.abs(y - ref)
+print(f"with that clamp: max |GELU error| = {err.max():.3e} at x = {xs[int(err.argmax())]:.4f}; at x = -12: {err[0]:.3e}, at x = 12: {err[-1]:.3e}")

@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
       {"tr_wgrad_gu", 22016, 4096, 9216, STLLM_EPI_STORE, 0, 1},
       {"tr_wgrad_qkv", 12288, 4096, 9216, STLLM_EPI_STORE, 0, 1},
       {"tr_wgrad_lm", 32000, 4096, 9216, STLLM_EPI_STORE, 0, 1},
+      {"vit_fc1_noact", 4112, 6144, 1408, STLLM_EPI_STORE, 0, 0},   // the fc1 shape without its GELU (epilogue timeline experiments)
   };
   int dev_lds = 0;
   CK(hipDeviceGetAttribute(&dev_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, 0));
@@ -238,6 +239,7 @@ int main(int argc, char** argv) {
       for (int g = 0; g < 256; ++g) {
         const int n = (int)h[g * 64];
         for (int i = 1; i < n; ++i) {
+          if (h[g * 64 + i] == 0) continue;
           const unsigned long long t = h[g * 64 + i] & 0x00ffffffffffffffull;
           if (t < t0) t0 = t;
           if (t > t1) t1 = t;
@@ -250,15 +252,18 @@ int main(int argc, char** argv) {
         const int n = (int)h[g * 64];
         if (n < 2) continue;
         if (g < 6 || g % 37 == 0) printf("  wg %3d:", g);
+        unsigned long long prev = 0;   // unused slots stay 0: skipped
         for (int i = 1; i < n; ++i) {
+          if (h[g * 64 + i] == 0) continue;
           const int tag = (int)(h[g * 64 + i] >> 56);
           const unsigned long long t = h[g * 64 + i] & 0x00ffffffffffffffull;
           if (g < 6 || g % 37 == 0) printf(" [%d]%llu", tag, t - t0);
-          if (i > 1) {
-            const int ptag = (int)(h[g * 64 + i - 1] >> 56);
-            sum[ptag][tag] += (double)(t - (h[g * 64 + i - 1] & 0x00ffffffffffffffull));
+          if (prev) {
+            const int ptag = (int)(prev >> 56);
+            sum[ptag][tag] += (double)(t - (prev & 0x00ffffffffffffffull));
             cnt[ptag][tag]++;
           }
+          prev = h[g * 64 + i];
         }
         if (g < 6 || g % 37 == 0) printf("\n");
       }
