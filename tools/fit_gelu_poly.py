@@ -2,8 +2,10 @@
 """Minimax fit of the GELU used by the 16-bit GEMM epilogues (csrc/common.h gelu_poly16):
     GELU(x) = x * Phi(x),  Phi(x) ~ 0.5 + xc * P(xc^2),  xc = clamp(x, -X0, X0),  P of degree DEG in t = x^2
 with the END-POINT CONSTRAINT X0 * P(X0^2) = 0.5, so that Phi(-X0) = 0 and Phi(X0) = 1 exactly: the clamp alone gives the two tails
-(no compare + select per element).  Linear program over a dense grid (scipy HiGHS); prints the coefficients in Horner order and the
-maximum absolute GELU error, evaluated in float32 Horner arithmetic as the kernel does.
+(no compare + select per element).  Linear program over a dense grid (scipy HiGHS), minimising the maximum error of PHI (so the GELU error
+grows like |x|: 1e-5 in the bulk |x| <= 1 where the activations live, 5e-5 at the clamp; a fit that levels the GELU error itself at 3.7e-5
+everywhere cost the fp16 mode 0.007 of logit error at full size); prints the coefficients in Horner order and the maximum absolute GELU
+error, evaluated in float32 Horner arithmetic as the kernel does.
     python tools/fit_gelu_poly.py [X0=4.3] [DEG=8]"""
 import sys
 
@@ -17,10 +19,10 @@ DEG = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 x = np.cos(np.linspace(0, np.pi / 2, 4001))[::-1] * X0            # Chebyshev-spaced grid on [0, X0]
 u = (x / X0) ** 2                                                    # scaled variable in [0, 1]
 phi_half = 0.5 * erf(x / np.sqrt(2.0))                               # Phi(x) - 0.5
-# error of GELU: x * (x * P(x^2) - (Phi - 0.5)), P in the Chebyshev basis of (2u - 1) for conditioning
+# error of Phi: x * P(x^2) - (Phi - 0.5), P in the Chebyshev basis of (2u - 1) for conditioning
 V = np.polynomial.chebyshev.chebvander(2 * u - 1, DEG)               # [n, DEG + 1]
-A = (x * x)[:, None] * V
-b = x * phi_half
+A = x[:, None] * V
+b = phi_half
 n = DEG + 1
 # variables: c[0..DEG], eps
 c_obj = np.zeros(n + 1); c_obj[-1] = 1.0
@@ -36,7 +38,7 @@ pu = np.polynomial.chebyshev.cheb2poly(cheb)                         # monomial 
 pw = np.polynomial.Polynomial(pu)
 pt = pw(np.polynomial.Polynomial([-1.0, 2.0 / (X0 * X0)]))           # substitute w = -1 + 2 t / X0^2
 coef = pt.coef                                                       # c0 + c1 t + ...
-print(f"X0 = {X0}, degree {DEG}: LP minimax |GELU error| = {r.x[-1]:.3e}")
+print(f"X0 = {X0}, degree {DEG}: LP minimax |Phi error| = {r.x[-1]:.3e}")
 print("Horner order (highest power first):")
 for c in coef[::-1]:
     print(f"  {np.float32(c)!r:>28}   {c:.17e}")
