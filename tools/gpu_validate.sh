@@ -1,3 +1,5 @@
+# Round-end validation on the GPU box: full GPU test suite, smoke(), the default bench line and a rocprofv3 kernel trace of a short bench run.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- "bash tools/gpu_validate.sh"   (outputs under gpurun_out/r3t/)
 mkdir -p gpurun_out/r3t
 (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > gpurun_out/r3t/gpu_tests.log; tail -2 gpurun_out/r3t/gpu_tests.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2) > gpurun_out/r3t/smoke.log; tail -1 gpurun_out/r3t/smoke.log
