@@ -169,7 +169,8 @@ int stllm_gemm(const stllm_gemm_args* args, void* stream);
 
 /* HIP-event timing of stllm_gemm launches on their launch stream, per calling thread (bench.py's roofline leg; also sees the launches of
  * the whole-stack entry points below).  mode 0 off | 1 every launch | 2 only launches whose kernel symbol — learned per (dtype, epilogue,
- * act, M, N, K) while mode 1 was on — equals target_symbol.  Every call starts a new, empty session.  _read synchronises record i's end
+ * act, M, N, K) while mode 1 was on — equals target_symbol | 3 every 7th of those (a sample: the event records sit between the kernels on
+ * the stream and cost the measured step ~3 us per timed launch; bench.py's timed region uses 3).  Every call starts a new, empty session.  _read synchronises record i's end
  * event and returns its kernel symbol (stllm_last_kernel naming), duration, algorithmic FLOPs (2 M N K) and shape. */
 int stllm_gemm_profile(int mode, const char* target_symbol);
 int stllm_gemm_profile_count(void);

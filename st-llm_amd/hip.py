@@ -363,9 +363,13 @@ class GemmProfiler:
         self.target = None
         _check(lib().stllm_gemm_profile(1, None), "stllm_gemm_profile")
 
-    def start_target(self, sym):
+    SAMPLE_EVERY = 7   # csrc/profile.cpp kSampleEvery
+
+    def start_target(self, sym, sampled=False):
+        """sampled: every 7th launch of `sym` only — an event pair around each of the 78 launches per step of the dominant GEMM symbol costs the
+        step 0.5 ms of 23.6 (`bench.py` / `bench.py --no-roofline` alternating on one box: 23.69 / 23.12 / 23.57 / 23.12 / 23.70 / 23.25)"""
         self.target = sym
-        _check(lib().stllm_gemm_profile(2, sym.encode()), "stllm_gemm_profile")
+        _check(lib().stllm_gemm_profile(3 if sampled else 2, sym.encode()), "stllm_gemm_profile")
 
     def stop(self):
         _check(lib().stllm_gemm_profile(0, None), "stllm_gemm_profile")
