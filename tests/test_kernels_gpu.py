@@ -340,6 +340,51 @@ BENCH_SHAPES = [(4112, 6144, 1408, "gelu"), (4112, 1408, 6144, "resid"), (4112, 
                 (576, 12288, 4096, "store"), (576, 4096, 11008, "resid"), (576, 4096, 4096, "resid"), (576, 32000, 4096, "store")]
 
 
+def test_gemm_profile_modes(hip):
+    """stllm_gemm_profile (what bench.py's roofline leg reads): mode 1 records every stllm_gemm launch with its kernel symbol, shape and
+    algorithmic FLOPs; mode 2 only launches of the target symbol; mode 3 every 7th of those (the timed region: the event records cost the
+    step they measure); a new session starts empty and mode 0 records nothing."""
+    dtype = "bf16"
+    a, _ = rnd("pa", (512, 256), dtype, 0.5)
+    w1, _ = rnd("pw1", (256, 256), dtype, 0.05)
+    w2, _ = rnd("pw2", (384, 256), dtype, 0.05)
+    prof = hip.GemmProfiler()
+    try:
+        prof.start_all()
+        for _ in range(3):
+            hip.gemm(a, w1, dtype=dtype)
+            hip.gemm(a, w2, dtype=dtype)
+        s = prof.summary()
+        assert sum(v["launches"] for v in s.values()) == 6
+        shapes = {k: v["launches"] for e in s.values() for k, v in e["shapes"].items()}
+        assert shapes == {"512x256x256": 3, "512x384x256": 3}, shapes
+        for e in s.values():
+            for k, v in e["shapes"].items():
+                M, N, K = map(int, k.split("x"))
+                assert v["flops"] == pytest.approx(2.0 * M * N * K * v["launches"]) and v["total_ms"] > 0
+        # the symbol of the first shape (both may share one symbol: count what the target mode must see)
+        sym = next(k for k, e in s.items() if "512x256x256" in e["shapes"])
+        per_round = sum(1 for k, e in s.items() if k == sym for _ in e["shapes"])
+        prof.start_target(sym)
+        for _ in range(14):
+            hip.gemm(a, w1, dtype=dtype)
+            hip.gemm(a, w2, dtype=dtype)
+        t = prof.summary()
+        assert set(t) == {sym} and t[sym]["launches"] == 14 * per_round, t
+        prof.start_target(sym, sampled=True)
+        for _ in range(14):
+            hip.gemm(a, w1, dtype=dtype)
+            hip.gemm(a, w2, dtype=dtype)
+        t = prof.summary()
+        n = 14 * per_round
+        assert t[sym]["launches"] == (n + hip.GemmProfiler.SAMPLE_EVERY - 1) // hip.GemmProfiler.SAMPLE_EVERY, t
+        prof.stop()
+        hip.gemm(a, w1, dtype=dtype)
+        assert prof.summary() == {}
+    finally:
+        prof.stop()
+
+
 @pytest.mark.parametrize("M,N,K,kind", BENCH_SHAPES)
 def test_gemm_bench_shapes_auto_dispatch(hip, M, N, K, kind):
     """the exact GEMM shapes bench.py times (T = 16 ViT rows 16 x 257 = 4112, Llama prefill S = 576), through the automatic
