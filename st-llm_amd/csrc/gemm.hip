@@ -921,7 +921,7 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   // Round 2, first version (2-buffer LDS ring): no gain inside bench.py, where the weights come from HBM (proj + fc2 5.39 ms per
   // step against 5.46 ms); with the 3-buffer ring of the 192 x 128 tile the harness measures the same time on cold weights as on
   // warm ones (tools/gemm_harness ... <cold MiB>, profiles/r02_w4_ring3.md) and the rule below is the default (-1 == 2).
-  if (g_w4_mode != 2 && g_w4_mode != -1) return false;
+  if (g_w4_mode != 2 && g_w4_mode != -1 && g_w4_mode != 3) return false;
   // exchange-free plans only: the one candidate with a K-split that the estimates favour, the Llama qkv GEMM (576 x 12288 x 4096 as
   // 256 whole 192 x 128 tiles + 32 tiles split 8 ways), measured 76.8 vs 81.3 us in the harness but 81.7 us inside bench.py
   // (profiles/r02c_bench_kernel_stats.md) — no gain, so the 128 x 128 kernel keeps it and no model GEMM depends on a w4 exchange
@@ -963,7 +963,12 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       int shape = 44, miw2 = 4;
       const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2);
       const int thin_bit = (a->epilogue == STLLM_EPI_STORE || a->epilogue == STLLM_EPI_RESID) ? 8 : 0;   // gemm_w4.inc: thin tail rows allowed
-      if (w4_wanted(p, heavy | thin_bit, &shape, p8_est)) {
+      // experiment switch (STLLM_GEMM_W4=3): the automatic rule, plus the Llama prefill qkv GEMM (ROPE epilogue, M < 1024) on the
+      // 192 x 128 one-wave tile with its K-split remainder — 78.5 vs 82.9 us in the harness, re-measured in the model every round
+      bool w4_go = w4_wanted(p, heavy | thin_bit, &shape, p8_est);
+      if (!w4_go && g_w4_mode == 3 && a->epilogue == STLLM_EPI_ROPE && p.M < 1024 && p.ws != nullptr &&
+          p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) { shape = 32; w4_go = true; }
+      if (w4_go) {
         const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
                                                       : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
         if (rc != STLLM_ERR_UNSUPPORTED) return rc;
