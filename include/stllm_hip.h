@@ -161,7 +161,7 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp)
  *   "attn_bwd_valu" = 0 (default) MFMA attention backward for 16-bit operands | 1 the VALU twins
- *   "norm_fast"  = 1 (default) | 0: round-1 LayerNorm / RMSNorm kernels
+ *   "norm_fast"  = 1 (default) one row per wave | 2: two rows per wave for >= 2048 short rows (bit-identical results, same speed: an A/B switch)
  *   "gemm_w4_odd" = 1 (default) the 192-column tiles (43 = 256 x 192, 33 = 192 x 192; 16-bit STORE epilogues) take part in the automatic
  *                  choice | 0 the round-2 choice (A/B inside one process: bench.py --ab) */
 int stllm_set_option(const char* key, int value);

@@ -7,24 +7,30 @@ namespace {
 
 constexpr int kMaxVec = 32;  // D <= 64 lanes * 4 floats * 32 = 8192
 
-template <typename T, bool RMS, int NV>
+template <typename T, bool RMS, int NV, int RW = 1>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int64_t ldx,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float eps, void* __restrict__ out_t, int64_t ldo_t,
                                                    float* __restrict__ out_f, int64_t ldo_f, int M, int D) {
+  // RW rows per wave (RW = 2 for the short rows of the ViT: the kernel is one dependent chain per wave — load, two reductions, store —
+  // and a launch of 4112 one-row waves was mostly dispatch + that chain's latency; two rows in flight per wave share gamma / beta and
+  // overlap their chains)
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
   const int nvec = D >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
-  float4 v[NV];
-  float s = 0.0f;
+  float4 v[RW][NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < RW; ++q) {
+    const int row = row0 + q < M ? row0 + q : M - 1;   // (a clamped duplicate of the last row: never stored)
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      v[q][i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  // gamma / beta are requested together with the row (round 3): behind the two reductions their L2 round trip was a second, fully exposed
+  // gamma / beta are requested together with the rows (round 3): behind the two reductions their L2 round trip was a second, fully exposed
   // latency in a kernel that is one dependent chain per wave (9.2 -> ~8 us at 4112 x 1408)
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
@@ -36,50 +42,73 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     gv[i] = g4[cc];
     if constexpr (!RMS) bv[i] = b4[cc];
   }
+  float s[RW], mean[RW], rstd[RW];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    if constexpr (RMS) s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
-    else s += v[i].x + v[i].y + v[i].z + v[i].w;
+  for (int q = 0; q < RW; ++q) {
+    s[q] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (RMS) s[q] += v[q][i].x * v[q][i].x + v[q][i].y * v[q][i].y + v[q][i].z * v[q][i].z + v[q][i].w * v[q][i].w;
+      else s[q] += v[q][i].x + v[q][i].y + v[q][i].z + v[q][i].w;
+    }
   }
-  s = wave_sum(s);
-  float mean = 0.0f, rstd;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {   // the RW reductions step by step side by side (wave_sum's order per row)
+#pragma unroll
+    for (int q = 0; q < RW; ++q) s[q] += __shfl_xor(s[q], o, 64);
+  }
   if constexpr (RMS) {
-    rstd = rsqrtf(s / (float)D + eps);
+#pragma unroll
+    for (int q = 0; q < RW; ++q) { mean[q] = 0.0f; rstd[q] = rsqrtf(s[q] / (float)D + eps); }
   } else {
-    mean = s / (float)D;
-    float q = 0.0f;
+    float qq[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+      mean[q] = s[q] / (float)D;
+      qq[q] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+          const float a = v[q][i].x - mean[q], b = v[q][i].y - mean[q], cc = v[q][i].z - mean[q], d = v[q][i].w - mean[q];
+          qq[q] += a * a + b * b + cc * cc + d * d;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int q = 0; q < RW; ++q) qq[q] += __shfl_xor(qq[q], o, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q) rstd[q] = rsqrtf(qq[q] / (float)D + eps);
+  }
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int row = row0 + q;
+    if (row >= M) continue;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
-      if (c < nvec) {
-        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-        q += a * a + b * b + cc * cc + d * d;
+      if (c >= nvec) continue;
+      const float4 g = gv[i];
+      float4 o;
+      o.x = (v[q][i].x - mean[q]) * rstd[q] * g.x; o.y = (v[q][i].y - mean[q]) * rstd[q] * g.y;
+      o.z = (v[q][i].z - mean[q]) * rstd[q] * g.z; o.w = (v[q][i].w - mean[q]) * rstd[q] * g.w;
+      if constexpr (!RMS) {
+        const float4 b = bv[i];
+        o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
       }
-    }
-    q = wave_sum(q);
-    rstd = rsqrtf(q / (float)D + eps);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    if (c >= nvec) continue;
-    const float4 g = gv[i];
-    float4 o;
-    o.x = (v[i].x - mean) * rstd * g.x; o.y = (v[i].y - mean) * rstd * g.y;
-    o.z = (v[i].z - mean) * rstd * g.z; o.w = (v[i].w - mean) * rstd * g.w;
-    if constexpr (!RMS) {
-      const float4 b = bv[i];
-      o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
-    }
-    if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
-    if (out_t) {
-      if constexpr (Elem<T>::kIsF32) {
-        reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
-      } else {
-        uint2 pk;
-        pk.x = Elem<T>::pack2(o.x, o.y);
-        pk.y = Elem<T>::pack2(o.z, o.w);
-        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
+      if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
+      if (out_t) {
+        if constexpr (Elem<T>::kIsF32) {
+          reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
+        } else {
+          uint2 pk;
+          pk.x = Elem<T>::pack2(o.x, o.y);
+          pk.y = Elem<T>::pack2(o.z, o.w);
+          reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
+        }
       }
     }
   }
@@ -231,6 +260,13 @@ int launch_nv(const float* x, int64_t ldx, const float* gamma, const float* beta
 #define STLLM_NORM_CASE(NV)                                                                                  \
   hipLaunchKernelGGL((norm_kernel<T, RMS, NV>), grid, block, 0, stream, x, ldx, gamma, beta, eps, out_t, ldo_t, \
                      out_f, ldo_f, M, D)
+  if (nv <= 6 && M >= 2048 && stllm_options().norm_fast == 2) {   // two rows per wave (option norm_fast = 2)
+    dim3 g2((M + 7) / 8);
+    if (nv <= 3) hipLaunchKernelGGL((norm_kernel<T, RMS, 3, 2>), g2, block, 0, stream, x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D);
+    else hipLaunchKernelGGL((norm_kernel<T, RMS, 6, 2>), g2, block, 0, stream, x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D);
+    STLLM_CHECK_LAUNCH(RMS ? "stllm_rmsnorm" : "stllm_layernorm");
+    return STLLM_OK;
+  }
   if (nv <= 3) STLLM_NORM_CASE(3);
   else if (nv <= 6) STLLM_NORM_CASE(6);
   else if (nv <= 16) STLLM_NORM_CASE(16);

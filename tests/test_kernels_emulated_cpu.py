@@ -343,6 +343,28 @@ def test_emulated_forward_norms(dtype):
 
 
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_emulated_norms_two_rows_per_wave(dtype):
+    """option norm_fast = 2: two rows per wave for many short rows (an odd row count: the last wave's second row is a clamped duplicate
+    that must not be stored)"""
+    M, D = 2049, 264
+    x, g, b = rnd(M, D, seed=70) * 2 + 0.1, rnd(D, seed=71) + 1, rnd(D, seed=72)
+    with _hipemu.emulated() as hip:
+        hip.set_option("norm_fast", 2)
+        try:
+            ln_t, ln_f = hip.layernorm(x, g, b, 1e-5, dtype=dtype, want_f32=True)
+            rm_t, rm_f = hip.rmsnorm(x, g, 1e-6, dtype=dtype, want_f32=True)
+        finally:
+            hip.set_option("norm_fast", 1)
+        one_t, one_f = hip.layernorm(x, g, b, 1e-5, dtype=dtype, want_f32=True)
+    wl_t, wl_f = C.layernorm(x, g, b, 1e-5, dtype=dtype, want_f32=True)
+    wr_t, wr_f = C.rmsnorm(x, g, 1e-6, dtype=dtype, want_f32=True)
+    for got, want, tol in ((ln_t, wl_t, TOL[dtype]), (ln_f, wl_f, 1e-5), (rm_t, wr_t, TOL[dtype]), (rm_f, wr_f, 1e-5)):
+        close(got, want, tol, "norm, two rows per wave")
+    assert torch.equal(ln_f, one_f) and torch.equal(ln_t, one_t), "two rows per wave != one row per wave"
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
 def test_emulated_forward_elementwise():
     a, bsrc, add = rnd(6, 40, seed=63), rnd(5, 40, seed=64), rnd(3, 40, seed=65)
     idx = torch.tensor([0, -1, 5, -5, 2, 2, -3], dtype=torch.int32)
