@@ -201,7 +201,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // GELU for 16-bit OUTPUTS of the GEMM epilogues: Phi(x) = 0.5 + xc * P(xc^2), xc = clamp(x, -X0, X0), P of degree 8 — a minimax fit of
 // 0.5 * erf(x / sqrt2) / x on |x| <= 4.3 (max |Phi error| 9.9e-6) under the END-POINT CONSTRAINT X0 * P(X0^2) = 0.5 (tools/fit_gelu_poly.py),
 // so that the clamp alone gives both tails: Phi(-X0) = 8.7e-11 and Phi(X0) = 1 in float32 at X0 = 4.2983036 (no compare + select per
-// element as in round 2).  |GELU error| <= 1.0e-5 |x|: 1.7e-5 on |x| <= 2, 5.1e-5 at the clamp (below the fp16 / bf16 rounding of any
+// element as in round 2).  |GELU error| <= 1.2e-5 |x| in float32: 1.7e-5 on |x| <= 2, 5.1e-5 at the clamp (below the fp16 / bf16 rounding of any
 // result of magnitude >= 0.1; in the far negative tail, where GELU itself is < 1e-3, the relative error reaches 1e-2).  13 packed VALU ops
 // per PAIR of values (round 2: 17) against ~12 + two quarter-rate transcendentals per value for the erf form.
 #define STLLM_GELU_X0 4.2983036f
