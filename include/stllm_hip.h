@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-typedef enum { STLLM_BF16 = 0, STLLM_F16 = 1, STLLM_F32 = 2 } stllm_dtype;
+/* STLLM_BF16X3 (ABI >= 5; stllm_gemm and the whole-stack entry points only): the "split" verify mode — fp32 activations and outputs, every GEMM
+ * run as THREE bf16 matrix-core products (A_hi W_hi + A_hi W_lo + A_lo W_hi, x = hi + lo in bf16) in one bf16 GEMM with K' = 3 K; the
+ * fp32 accuracy class (~2^-16 relative per product) at 3x the bf16 FLOPs instead of the 16x of the exact fp32 MFMA.  See stllm_gemm. */
+typedef enum { STLLM_BF16 = 0, STLLM_F16 = 1, STLLM_F32 = 2, STLLM_BF16X3 = 3 } stllm_dtype;
 
 typedef enum {
   STLLM_OK = 0,
@@ -77,6 +80,10 @@ const char* stllm_last_kernel(void);
  * PATCH : A is ignored — the A operand is gathered from `frames` f32 [n_frames,3,224,224]
  *         (implicit GEMM, eva_vit.py:196-204); M = n_frames*256; K = 588 padded (W zero-padded to
  *         ldw); out_f32 = x[n_frames*257, ldo]; `aux` = pos_embed f32[257,N].
+ * dtype STLLM_BF16X3: A is f32 [M,lda]; W is bf16 [N, ldw >= 3 K] = stllm_split3_rows(weight, side 1) — (hi | lo | hi) along K;
+ *         every output is f32 (STORE / SWIGLU / ROPE write f32 [M,ldo]; act = exact erf GELU / ReLU); K % 64 == 0; PATCH and a_norm_*
+ *         are rejected.  Needs split_ws (below).  Internally: split A -> bf16 [M, 3 K] (hi | hi | lo), ONE bf16 GEMM with K' = 3 K and
+ *         fp32 output on the kernels above, then the activation / SwiGLU / RoPE as an fp32 row pass.
  */
 typedef struct {
   int dtype;          /* stllm_dtype */
@@ -109,24 +116,17 @@ typedef struct {
    * a_norm_x: fp32 rows [M, K], row stride a_norm_ldx elements; a_norm_gamma: fp32 [K].  A / lda are ignored (may be NULL / 0).
    * Outside the decode regime the call is rejected (STLLM_ERR_UNSUPPORTED): run stllm_rmsnorm first. */
   const float* a_norm_x; int64_t a_norm_ldx; const float* a_norm_gamma; float a_norm_eps;
-  /* optional, ABI version >= 4 (16-bit dtypes): LayerNorm FOLDED into the two GEMMs around it — eva_vit.py:173-180, the
-   * `self.norm1(x)` / `self.norm2(x)` in front of attn.qkv and mlp.fc1 — so that no normalisation kernel runs between them:
-   *   PRODUCER (epilogue RESID, the GEMM that writes the stream: attn.proj / mlp.fc2): besides out_f32 it writes fold_out_t = T(out) (row
-   *     stride fold_ldo_t elements) and fold_stats_out[m][g] = (sum, sum of squares) of the fp32 row m over columns 64 g .. 64 g + 63
-   *     (f32 [M][N / 64][2]).
-   *   CONSUMER (epilogue STORE, 16-bit output): A = that copy, W = gamma (.) W (row-wise: W'[n, k] = gamma[k] W[n, k], packed by the caller),
-   *     bias = W beta + b, fold_colsum[n] = sum_k W'[n, k]; fold_stats_in / fold_groups (= K / 64) / fold_eps give the row statistics:
-   *       out = act(rstd_m * (acc - mean_m * fold_colsum[n]) + bias[n])        (== act(LayerNorm(x) W^T + b) up to where A is rounded)
-   * Only the one-wave-per-SIMD kernels implement it (no fallback): ask stllm_gemm_fold_supported() first. */
-  void* fold_out_t; int64_t fold_ldo_t; float* fold_stats_out;
-  const float* fold_stats_in; int fold_groups; float fold_eps; const float* fold_colsum;
+  /* ABI version >= 5, dtype STLLM_BF16X3 only: >= stllm_gemm_split_ws_bytes(M, N, K, epilogue) bytes of device memory, 16-byte aligned, private
+   * to the launch stream, no initialisation (the split A operand and, for SWIGLU, the fp32 gate/up columns).  (ABI 4's fold_* fields —
+   * LayerNorm folded into the GEMMs, measured slower than the LayerNorm kernels — were removed with their kernels in ABI 5.) */
+  void* split_ws; int64_t split_ws_bytes;
 } stllm_gemm_args;
-/* 1 when both halves of the folded LayerNorm can run for a stream of M rows x D columns (producer: N = D) whose consumer has n_out output
- * columns and K = D (gelu: the consumer's activation); host-only. */
-int stllm_gemm_fold_supported(int dtype, int M, int D, int n_out, int gelu);
-/* The stream's first row statistics (before any producer GEMM has run): out_t = T(x), stats[m][g] = (sum, sum of squares) over columns
- * 64 g .. 64 g + 63 of the fp32 rows x [M, D] (D % 64 == 0) — same layout as fold_stats_out. */
-int stllm_row_stats(int dtype, const float* x, int64_t ldx, void* out_t, int64_t ldo_t, float* stats, int M, int D, void* stream);
+int64_t stllm_gemm_split_ws_bytes(int M, int N, int K, int epilogue);
+/* x f32 [M, K] (row stride ldx; rows_per_batch / batch_stride: the 2-level row indexing of stllm_gemm_args, 0 = flat) ->
+ * out bf16 [M, ldo >= 3 K]: hi = bf16(x), lo = bf16(x - hi), laid out (hi | hi | lo) along K for weight_side == 0 (the A operand) and
+ * (hi | lo | hi) for weight_side != 0 (the weight: packed once).  K % 4 == 0. */
+int stllm_split3_rows(const float* x, int64_t ldx, int rows_per_batch, int64_t batch_stride, void* out, int64_t ldo, int M, int K,
+                      int weight_side, void* stream);
 int64_t stllm_gemm_workspace_bytes(void);
 /* Synchronises `stream` and returns 0 when no GEMM launch that used `workspace` ever gave up waiting for a peer workgroup
  * (the split-K exchanges poll with a bound instead of hanging the GPU when not all workgroups are resident, e.g. on a
@@ -190,18 +190,12 @@ typedef struct {
   const float* n2w; const float* n2b; float e2;
   const void* wfc1; int64_t ld_fc1; const float* bfc1;     /* [hidden, dim] */
   const void* wfc2; int64_t ld_fc2; const float* bfc2;     /* [dim, hidden] */
-  /* optional (NULL: the block runs its LayerNorms as kernels): norm1 folded into qkv, norm2 into fc1 (stllm_gemm_args fold_*):
-   * wqkv_f = gamma1 (.) wqkv (same dtype and stride as wqkv), bqkv_f = wqkv beta1 + bqkv, cs_qkv[n] = sum_k wqkv_f[n, k]; likewise fc1 */
-  const void* wqkv_f; const float* bqkv_f; const float* cs_qkv;
-  const void* wfc1_f; const float* bfc1_f; const float* cs_fc1;
 } stllm_vit_block_weights;
 typedef struct {
   int dtype; int n_seq; int seq_len; int num_heads; int dim; int hidden;
   float* x; int64_t ldx;                       /* fp32 residual stream [n_seq * seq_len, dim], updated in place */
   void* scratch; int64_t scratch_bytes;        /* >= stllm_vit_blocks_scratch_bytes(...), 256-byte aligned, no initialisation */
   void* workspace; int64_t workspace_bytes;    /* the stllm_gemm workspace of the launch stream */
-  int fold_norms;                              /* != 0: run the LayerNorms folded into the GEMMs where every block carries the folded weights and
-                                                  stllm_gemm_fold_supported() agrees (16-bit dtypes); otherwise they run as kernels */
 } stllm_vit_blocks_args;
 int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden);
 /* VisionTransformer.forward_features' block loop (eva_vit.py:336-339; Block.forward :173-180) for n_blocks consecutive blocks */

@@ -937,15 +937,6 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     const int gemv_mode = o_.gemm_gemv, g_sk_mode = o_.gemm_sk, g_p8_mode = o_.gemm_p8, g_w4_mode = o_.gemm_w4;
     const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
-    if (p.fold_out_t || p.fold_stats_in) {   // LayerNorm folded into the GEMMs: gemm_w4.inc FOLD variants only (no fallback: the caller asks first)
-      int rc = STLLM_ERR_UNSUPPORTED;
-      if (p.ws != nullptr && p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4 && a->epilogue != STLLM_EPI_PATCH) {
-        const int shape = p.fold_out_t ? 32 : stllm_gemm_w4_fold_consumer_shape(p.M, p.N, p.K, a->act == STLLM_ACT_GELU);
-        if (shape) rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream) : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
-      }
-      if (rc == STLLM_ERR_UNSUPPORTED) stllm_set_error("stllm_gemm(fold_*): no folded-LayerNorm kernel for this problem (M=%d N=%d K=%d epilogue %d): ask stllm_gemm_fold_supported first", p.M, p.N, p.K, a->epilogue);
-      return rc;
-    }
     if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
       const int rc = a->epilogue != STLLM_EPI_PATCH ? stllm_gemv_launch(a->dtype, a->epilogue, p, stream) : STLLM_ERR_UNSUPPORTED;
       if (rc == STLLM_ERR_UNSUPPORTED) stllm_set_error("stllm_gemm(a_norm): shape outside the decode regime (M=%d N=%d K=%d): run stllm_rmsnorm first", p.M, p.N, p.K);
@@ -993,13 +984,19 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
 
 }  // namespace
 
+int stllm_gemm_bf16x3(const stllm_gemm_args* a, void* stream);   // split3.hip
 int stllm_prof_begin(const stllm_gemm_args* a, void* stream);     // profile.cpp
-void stllm_prof_end(int idx, const stllm_gemm_args* a, void* stream);
+void stllm_prof_end(int idx, int rc, const stllm_gemm_args* a, void* stream);
 
 extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   STLLM_CHECK_ARG(a != nullptr, "stllm_gemm: null args");
-  STLLM_CHECK_ARG(a->dtype >= STLLM_BF16 && a->dtype <= STLLM_F32, "stllm_gemm: bad dtype %d", a->dtype);
+  STLLM_CHECK_ARG(a->dtype >= STLLM_BF16 && a->dtype <= STLLM_BF16X3, "stllm_gemm: bad dtype %d", a->dtype);
+  if (a->dtype == STLLM_BF16X3) {   // split3.hip: split A, ONE bf16 GEMM with K' = 3 K (back through this entry point), fp32 post-epilogue
+    STLLM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 128 == 0 && a->out != nullptr && aligned16(a->out) && a->W && aligned16(a->W),
+                    "stllm_gemm(BF16X3): empty problem, N %% 128 != 0 or null / misaligned W / out (M=%d N=%d K=%d)", a->M, a->N, a->K);
+    return stllm_gemm_bf16x3(a, stream_);
+  }
   const int eb = a->dtype == STLLM_F32 ? 4 : 2;
   const int panel = kRowBytes / eb;
   STLLM_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "stllm_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -1034,13 +1031,6 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   if (a->epilogue == STLLM_EPI_ROPE)
     STLLM_CHECK_ARG(a->aux0 && a->aux1 && a->rope_seq > 0 && a->rope_cols % 128 == 0, "stllm_gemm(ROPE): need cos/sin tables, rope_seq, rope_cols%%128==0");
 
-  if (a->fold_out_t || a->fold_stats_out)
-    STLLM_CHECK_ARG(a->fold_out_t && a->fold_stats_out && a->epilogue == STLLM_EPI_RESID && a->dtype != STLLM_F32 && (a->fold_ldo_t * 2) % 8 == 0 &&
-                        (reinterpret_cast<uintptr_t>(a->fold_out_t) & 7) == 0 && (reinterpret_cast<uintptr_t>(a->fold_stats_out) & 7) == 0,
-                    "stllm_gemm(fold producer): needs RESID, a 16-bit dtype, fold_out_t + fold_stats_out (8-byte aligned)");
-  if (a->fold_stats_in)
-    STLLM_CHECK_ARG(a->fold_colsum && a->fold_groups > 0 && a->fold_groups * 64 == a->K && a->epilogue == STLLM_EPI_STORE && !a->out_is_f32 && a->dtype != STLLM_F32 &&
-                        aligned16(a->fold_stats_in), "stllm_gemm(fold consumer): needs STORE to a 16-bit output, fold_colsum, fold_groups * 64 == K");
   GemmParams p{};
   p.A = reinterpret_cast<const char*>(a->A); p.lda_b = a->lda * eb;
   p.W = reinterpret_cast<const char*>(a->W); p.ldw_b = a->ldw * eb;
@@ -1051,8 +1041,6 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   p.debug = stllm_options().gemm_debug;
   p.ws = reinterpret_cast<char*>(a->workspace); p.ws_bytes = a->workspace_bytes;
   p.nx = a->a_norm_x; p.nx_ld = a->a_norm_ldx; p.ngamma = a->a_norm_gamma; p.neps = a->a_norm_eps;
-  p.fold_out_t = a->fold_out_t; p.fold_ldo_t = a->fold_ldo_t; p.fold_stats_out = a->fold_stats_out;
-  p.fold_stats_in = a->fold_stats_in; p.fold_groups = a->fold_groups; p.fold_eps = a->fold_eps; p.fold_colsum = a->fold_colsum;
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
   p.o_rpb = a->o_rows_per_batch; p.o_bs = a->o_batch_stride;
   const int prof_rec = stllm_prof_begin(a, stream_);   // profile.cpp: HIP events around this launch when the caller asked for them
@@ -1062,19 +1050,10 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
     case STLLM_F16: rc = dispatch_epi<f16_t>(a, p, stream); break;
     default: rc = dispatch_epi<float>(a, p, stream); break;
   }
-  stllm_prof_end(prof_rec, a, stream_);
+  stllm_prof_end(prof_rec, rc, a, stream_);
   return rc;
 }
 
-
-// Can the folded-LayerNorm pair run for a stream of M rows x D columns whose consumers have n_out output columns?  (host-only)
-extern "C" int stllm_gemm_fold_supported(int dtype, int M, int D, int n_out, int gelu) {
-  if (dtype != STLLM_BF16 && dtype != STLLM_F16) return 0;
-  if (M <= 0 || D % 128 || D % 64 || n_out % 192 || n_out % 128) return 0;
-  int plan[5];
-  if (stllm_gemm_w4_plan(M, D, D, 1 | 8, 32, plan) != STLLM_OK || plan[2] != 1) return 0;   // producer with K = D (proj); other K: asked separately
-  return stllm_gemm_w4_fold_consumer_shape(M, n_out, D, gelu) != 0;
-}
 
 extern "C" int stllm_gemm_workspace_status(const void* workspace, void* stream_) {
   if (!workspace) return 0;

@@ -24,9 +24,6 @@ struct GemmParams {
   int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
   const float* nx; int64_t nx_ld; const float* ngamma; float neps;   // GEMV only: A := RMSNorm(nx) * ngamma (fp32 rows, stride nx_ld elements)
   int w4_thin;                     // gemm_w4 only: the last M % tile_rows (<= 32) rows are computed outside the tile grid (0 = none)
-  // LayerNorm folded into the GEMMs (gemm_w4.inc FOLD): producer outputs / consumer inputs (stllm_hip.h: fold_*)
-  void* fold_out_t; int64_t fold_ldo_t; float* fold_stats_out;
-  const float* fold_stats_in; int fold_groups; float fold_eps; const float* fold_colsum;
 };
 
 constexpr int kRowBytes = 128;  // one K panel row
@@ -70,5 +67,4 @@ float stllm_gemm_p8_estimate_us(int M, int N, int K, int heavy_epilogue, int* mi
 // same workspace, same epilogues and return codes as the phased kernel
 int stllm_gemm_w4_launch_bf16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
 int stllm_gemm_w4_launch_f16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
-int stllm_gemm_w4_fold_consumer_shape(int M, int N, int K, int gelu);   // tile (43 / 33) of the folded-LayerNorm consumer, 0 = none
 float stllm_gemm_w4_estimate_us(int M, int N, int K, int heavy_epilogue, int* shape, int* split);   // split = K slices of the remainder tiles (1: none)

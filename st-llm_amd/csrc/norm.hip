@@ -198,46 +198,6 @@ __global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__
   }
 }
 
-// Row statistics for the folded LayerNorm (stllm_hip.h: stllm_row_stats): one wave per row; out_t = T(x), stats[m][g] = (sum, sum of squares)
-// of columns 64 g .. 64 g + 63.  Lane l of chunk i holds columns 4 (l + 64 i) .. + 3: sixteen consecutive lanes = one 64-column group.
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t ldx, void* __restrict__ out_t, int64_t ldo_t,
-                                                        float* __restrict__ stats, int M, int D) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int nvec = D >> 2, ng = D >> 6;
-  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
-  float4 v[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + i * 64;
-    float s = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    float q = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      s += __shfl_xor(s, o, 64);
-      q += __shfl_xor(q, o, 64);
-    }
-    const int g = c >> 4;
-    if ((lane & 15) == 0 && g < ng) {
-      stats[((int64_t)row * ng + g) * 2] = s;
-      stats[((int64_t)row * ng + g) * 2 + 1] = q;
-    }
-    if (c < nvec) {
-      uint2 pk;
-      pk.x = Elem<T>::pack2(v[i].x, v[i].y);
-      pk.y = Elem<T>::pack2(v[i].z, v[i].w);
-      reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
-    }
-  }
-}
-
 template <typename T, bool RMS>
 int launch_nv(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out_t,
               int64_t ldo_t, float* out_f, int64_t ldo_f, int M, int D, hipStream_t stream) {
@@ -302,27 +262,6 @@ extern "C" int stllm_layernorm(int dtype, const float* x, int64_t ldx, const flo
                                int D, void* stream) {
   return norm_entry<false>(dtype, x, ldx, gamma, beta, eps, out_t, ldo_t, out_f32, ldo_f, M, D,
                            reinterpret_cast<hipStream_t>(stream));
-}
-
-extern "C" int stllm_row_stats(int dtype, const float* x, int64_t ldx, void* out_t, int64_t ldo_t, float* stats, int M, int D, void* stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  STLLM_CHECK_ARG(M > 0 && D > 0 && D % 64 == 0 && D <= 64 * 4 * 16, "stllm_row_stats: bad M=%d D=%d (D %% 64 == 0, D <= 4096)", M, D);
-  STLLM_CHECK_ARG(x && out_t && stats && ldx % 4 == 0 && aligned16(x) && ldo_t % 4 == 0 && (reinterpret_cast<uintptr_t>(out_t) & 7) == 0,
-                  "stllm_row_stats: null / misaligned buffers");
-  STLLM_CHECK_ARG(dtype == STLLM_BF16 || dtype == STLLM_F16, "stllm_row_stats: 16-bit dtypes only (dtype %d)", dtype);
-  const int nv = ((D >> 2) + 63) / 64;
-  dim3 grid((M + 3) / 4), block(256);
-#define STLLM_RS_CASE(TT, NV) hipLaunchKernelGGL((row_stats_kernel<TT, NV>), grid, block, 0, stream, x, ldx, out_t, ldo_t, stats, M, D)
-  if (dtype == STLLM_BF16) {
-    if (nv <= 6) STLLM_RS_CASE(bf16_t, 6);
-    else STLLM_RS_CASE(bf16_t, 16);
-  } else {
-    if (nv <= 6) STLLM_RS_CASE(f16_t, 6);
-    else STLLM_RS_CASE(f16_t, 16);
-  }
-#undef STLLM_RS_CASE
-  STLLM_CHECK_LAUNCH("stllm_row_stats");
-  return STLLM_OK;
 }
 
 extern "C" int stllm_rmsnorm(int dtype, const float* x, int64_t ldx, const float* gamma, float eps, void* out_t,

@@ -18,6 +18,7 @@ namespace {
 struct Rec { hipEvent_t s, e; const char* sym; double flops; int m, n, k; };
 typedef std::tuple<int, int, int, int, int, int, int> Key;   // dtype, epilogue, act, out_is_f32, M, N, K
 constexpr unsigned kSampleEvery = 7;
+constexpr size_t kMaxRecs = 1 << 16;   // records (event pairs) per session
 struct Prof {
   int mode = 0;                       // 0 off | 1 every launch | 2 launches whose symbol (learned in mode 1) equals `target` | 3: every 7th of those
   unsigned seen = 0;                  // mode 3: launches of the target so far
@@ -54,20 +55,29 @@ int stllm_prof_begin(const stllm_gemm_args* a, void* stream) {
     // serving two alternating shapes (ViT proj / fc2) is sampled on both.
     if (p.mode == 3 && (p.seen++ % kSampleEvery) != 0) return -1;
   }
+  if (p.recs.size() >= kMaxRecs) return -1;   // a session left in mode 1 for a long run: keep what we have, stop recording (stllm_gemm_profile starts afresh)
   Rec r;
   r.s = take_event(p);
   r.e = take_event(p);
+  if (!r.s || !r.e) return -1;                // event creation failed: no record rather than a read error later
   r.sym = "";
   r.flops = 2.0 * a->M * a->N * a->K;
   r.m = a->M; r.n = a->N; r.k = a->K;
-  (void)hipEventRecord(r.s, reinterpret_cast<hipStream_t>(stream));
+  if (hipEventRecord(r.s, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) { p.pool.push_back(r.s); p.pool.push_back(r.e); return -1; }
   p.recs.push_back(r);
   return (int)p.recs.size() - 1;
 }
 
-void stllm_prof_end(int idx, const stllm_gemm_args* a, void* stream) {
+void stllm_prof_end(int idx, int rc, const stllm_gemm_args* a, void* stream) {
   if (idx < 0) return;
   Prof& p = prof();
+  if (rc != STLLM_OK || idx != (int)p.recs.size() - 1) {   // the dispatch failed: nothing ran, stllm_last_kernel() still names the PREVIOUS launch —
+    if (idx == (int)p.recs.size() - 1) {                   // drop the record, learn no symbol for this shape
+      p.pool.push_back(p.recs[idx].s); p.pool.push_back(p.recs[idx].e);
+      p.recs.pop_back();
+    }
+    return;
+  }
   Rec& r = p.recs[idx];
   (void)hipEventRecord(r.e, reinterpret_cast<hipStream_t>(stream));
   r.sym = stllm_last_kernel();

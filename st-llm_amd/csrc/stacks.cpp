@@ -13,7 +13,9 @@ void stllm_set_error(const char* fmt, ...);
 namespace {
 
 inline int64_t up256(int64_t v) { return (v + 255) / 256 * 256; }
-inline int esize(int dtype) { return dtype == STLLM_F32 ? 4 : 2; }
+inline int esize(int dtype) { return (dtype == STLLM_F32 || dtype == STLLM_BF16X3) ? 4 : 2; }   // activations between the GEMMs
+inline int act_dtype(int dtype) { return dtype == STLLM_BF16X3 ? STLLM_F32 : dtype; }            // split mode: fp32 norms / attention
+inline bool dtype_ok(int dtype) { return dtype >= STLLM_BF16 && dtype <= STLLM_BF16X3; }
 
 struct Carver {
   char* base;
@@ -27,13 +29,21 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
-stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes) {
+stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes, void* split_ws, int64_t split_ws_bytes) {
   stllm_gemm_args g;
   memset(&g, 0, sizeof(g));
   g.dtype = dtype;
   g.workspace = ws;
   g.workspace_bytes = ws_bytes;
+  g.split_ws = split_ws;
+  g.split_ws_bytes = split_ws_bytes;
   return g;
+}
+
+// split workspace that serves every GEMM of a decoder layer: the widest split A operand (down_proj: K = inter) next to the fp32 gate/up columns
+inline int64_t llama_split_ws(int M, int hidden, int inter) {
+  const int64_t a = stllm_gemm_split_ws_bytes(M, hidden, inter, STLLM_EPI_RESID), b = stllm_gemm_split_ws_bytes(M, 2 * inter, hidden, STLLM_EPI_SWIGLU);
+  return a > b ? a : b;
 }
 
 }  // namespace
@@ -45,9 +55,11 @@ stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes) {
   } while (0)
 
 extern "C" int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden) {
-  if (n_seq <= 0 || seq_len <= 0 || dim <= 0 || hidden <= 0) return -1;
+  if (n_seq <= 0 || seq_len <= 0 || dim <= 0 || hidden <= 0 || !dtype_ok(dtype)) return -1;
   const int64_t M = (int64_t)n_seq * seq_len, e = esize(dtype);
-  return up256(M * dim * e) * 3 + up256(M * 3 * dim * e) + up256(M * hidden * e) + up256(M * (dim / 64 + 1) * 8);
+  int64_t need = up256(M * dim * e) * 2 + up256(M * 3 * dim * e) + up256(M * hidden * e);
+  if (dtype == STLLM_BF16X3) need += up256(stllm_gemm_split_ws_bytes((int)M, dim, hidden > dim ? hidden : dim, STLLM_EPI_STORE));   // the split A operand of the widest GEMM
+  return need;
 }
 
 // eva_vit.py:173-180 (Block.forward, gamma_1 / gamma_2 None) x n_blocks on the flat fp32 stream, in place:
@@ -55,74 +67,68 @@ extern "C" int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_
 //   [fc1 GEMM + bias + GELU] -> [fc2 GEMM + bias + residual]
 extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_block_weights* blocks, int n_blocks, void* stream) {
   if (!a || (!blocks && n_blocks > 0) || n_blocks < 0) { stllm_set_error("stllm_vit_blocks: null arguments"); return STLLM_ERR_BAD_SHAPE; }
-  if (a->dim % a->num_heads != 0 || !a->x || !a->scratch) { stllm_set_error("stllm_vit_blocks: bad dims / null buffers"); return STLLM_ERR_BAD_SHAPE; }
+  if (!dtype_ok(a->dtype)) { stllm_set_error("stllm_vit_blocks: bad dtype %d", a->dtype); return STLLM_ERR_BAD_DTYPE; }
+  if (a->num_heads <= 0 || a->dim <= 0 || a->hidden <= 0 || a->n_seq <= 0 || a->seq_len <= 0 || a->dim % a->num_heads != 0 || a->ldx < a->dim || !a->x || !a->scratch) {
+    stllm_set_error("stllm_vit_blocks: bad dims (heads %d, dim %d, hidden %d, ldx %lld) / null buffers", a->num_heads, a->dim, a->hidden, (long long)a->ldx);
+    return STLLM_ERR_BAD_SHAPE;
+  }
   const int64_t need = stllm_vit_blocks_scratch_bytes(a->dtype, a->n_seq, a->seq_len, a->dim, a->hidden);
   if (need < 0 || a->scratch_bytes < need) {
     stllm_set_error("stllm_vit_blocks: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
     return STLLM_ERR_BAD_SHAPE;
   }
   const int M = a->n_seq * a->seq_len, D = a->dim, hd = D / a->num_heads, e = esize(a->dtype);
+  const int adt = act_dtype(a->dtype);   // norms / attention: the activations' dtype (fp32 in the split mode)
   Carver c(a->scratch, a->scratch_bytes);
   char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* qkv = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
   char* g1 = reinterpret_cast<char*>(c.take((int64_t)M * a->hidden * e));
-  char* xb = reinterpret_cast<char*>(c.take((int64_t)M * D * e));                                 // folded norms: T(x)
-  float* st = reinterpret_cast<float*>(c.take((int64_t)M * (D / 64 + 1) * 8));                    // ... and its row partials [M][D / 64][2]
-  // LayerNorm folded into the GEMMs (stllm_hip.h fold_*): every block must carry the folded weights and both consumers must have a kernel
-  bool fold = a->fold_norms != 0 && n_blocks > 0 && D % 64 == 0 && stllm_gemm_fold_supported(a->dtype, M, D, 3 * D, 0) &&
-              stllm_gemm_fold_supported(a->dtype, M, D, a->hidden, 1);
-  for (int b = 0; b < n_blocks && fold; ++b) fold = blocks[b].wqkv_f && blocks[b].bqkv_f && blocks[b].cs_qkv && blocks[b].wfc1_f && blocks[b].bfc1_f && blocks[b].cs_fc1;
+  void* sws = nullptr;
+  int64_t sws_bytes = 0;
+  if (a->dtype == STLLM_BF16X3) {
+    sws_bytes = stllm_gemm_split_ws_bytes(M, D, a->hidden > D ? a->hidden : D, STLLM_EPI_STORE);
+    sws = c.take(sws_bytes);
+  }
   float scale = 1.0f;
   {   // hd ** -0.5 exactly as the host path computes it (Python float -> float32)
     double s = 1.0;
     s = 1.0 / __builtin_sqrt((double)hd);
     scale = (float)s;
   }
-  if (fold) STACK_TRY(stllm_row_stats(a->dtype, a->x, a->ldx, xb, D, st, M, D, stream));
   for (int b = 0; b < n_blocks; ++b) {
     const stllm_vit_block_weights& w = blocks[b];
-    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
-    if (fold) {   // norm1 inside the qkv GEMM: A = T(x), W = gamma1 (.) wqkv, row statistics from the partials
-      g.epilogue = STLLM_EPI_STORE; g.A = xb; g.lda = D; g.W = w.wqkv_f; g.ldw = w.ld_qkv; g.bias = w.bqkv_f;
-      g.fold_stats_in = st; g.fold_groups = D / 64; g.fold_eps = w.e1; g.fold_colsum = w.cs_qkv;
-    } else {
-      STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
-      g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
-    }
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+    STACK_TRY(stllm_layernorm(adt, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
+    g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
     g.out = qkv; g.ldo = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     const int64_t rs = 3 * D, bs = (int64_t)a->seq_len * rs;
-    STACK_TRY(stllm_attention(a->dtype, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
+    STACK_TRY(stllm_attention(adt, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
                               (int64_t)a->seq_len * D, D, a->n_seq, a->num_heads, a->seq_len, a->seq_len, hd, scale, 0, nullptr, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wproj; g.ldw = w.ld_proj; g.bias = w.bproj;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
-    if (fold) { g.fold_out_t = xb; g.fold_ldo_t = D; g.fold_stats_out = st; }   // proj also writes T(x) and the row partials norm2 needs
     STACK_TRY(stllm_gemm(&g, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
-    if (fold) {
-      g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = xb; g.lda = D; g.W = w.wfc1_f; g.ldw = w.ld_fc1; g.bias = w.bfc1_f;
-      g.fold_stats_in = st; g.fold_groups = D / 64; g.fold_eps = w.e2; g.fold_colsum = w.cs_fc1;
-    } else {
-      STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
-      g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
-    }
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+    STACK_TRY(stllm_layernorm(adt, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
+    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
     g.out = g1; g.ldo = a->hidden; g.M = M; g.N = a->hidden; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = g1; g.lda = a->hidden; g.W = w.wfc2; g.ldw = w.ld_fc2; g.bias = w.bfc2;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->hidden;
-    if (fold && b + 1 < n_blocks) { g.fold_out_t = xb; g.fold_ldo_t = D; g.fold_stats_out = st; }   // (the last block's output is normalised by the caller)
     STACK_TRY(stllm_gemm(&g, stream));
   }
   return STLLM_OK;
 }
 
 extern "C" int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, int inter) {
-  if (B <= 0 || S <= 0 || hidden <= 0 || inter <= 0) return -1;
+  if (B <= 0 || S <= 0 || hidden <= 0 || inter <= 0 || !dtype_ok(dtype)) return -1;
   const int64_t M = (int64_t)B * S, e = esize(dtype);
-  return up256(M * hidden * e) * 2 + up256(M * 3 * hidden * e) + up256(M * inter * e);
+  int64_t need = up256(M * hidden * e) * 2 + up256(M * 3 * hidden * e) + up256(M * inter * e);
+  if (dtype == STLLM_BF16X3) need += up256(llama_split_ws((int)M, hidden, inter));
+  return need;
 }
 
 // HF LlamaDecoderLayer x n_layers in prefill form (spec modeling_llama_mem.py:61-316) on the flat fp32 stream, in place:
@@ -131,8 +137,10 @@ extern "C" int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int
 //   into its cache buffer [B, cache_max_len, 3 * hidden] (rows (b, s) at b * cache_max_len + s) and attended in place.
 extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_llama_layer_weights* layers, int n_layers, void* stream) {
   if (!a || (!layers && n_layers > 0) || n_layers < 0) { stllm_set_error("stllm_llama_layers: null arguments"); return STLLM_ERR_BAD_SHAPE; }
-  if (!a->x || !a->scratch || !a->rope_cos || !a->rope_sin || a->hidden % a->n_heads != 0) {
-    stllm_set_error("stllm_llama_layers: bad dims / null buffers");
+  if (!dtype_ok(a->dtype)) { stllm_set_error("stllm_llama_layers: bad dtype %d", a->dtype); return STLLM_ERR_BAD_DTYPE; }
+  if (a->n_heads <= 0 || a->hidden <= 0 || a->inter <= 0 || a->B <= 0 || a->S <= 0 || a->hidden % a->n_heads != 0 || a->ldx < a->hidden ||
+      !a->x || !a->scratch || !a->rope_cos || !a->rope_sin) {
+    stllm_set_error("stllm_llama_layers: bad dims (heads %d, hidden %d, inter %d, ldx %lld) / null buffers", a->n_heads, a->hidden, a->inter, (long long)a->ldx);
     return STLLM_ERR_BAD_SHAPE;
   }
   const int64_t need = stllm_llama_layers_scratch_bytes(a->dtype, a->B, a->S, a->hidden, a->inter);
@@ -150,11 +158,18 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
   char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* qkv_s = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
   char* gu = reinterpret_cast<char*>(c.take((int64_t)M * a->inter * e));
+  void* sws = nullptr;
+  int64_t sws_bytes = 0;
+  if (a->dtype == STLLM_BF16X3) {
+    sws_bytes = llama_split_ws(M, D, a->inter);
+    sws = c.take(sws_bytes);
+  }
+  const int adt = act_dtype(a->dtype);
   const float scale = (float)(1.0 / __builtin_sqrt((double)hd));
   for (int l = 0; l < n_layers; ++l) {
     const stllm_llama_layer_weights& w = layers[l];
-    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln1, a->eps, h, D, nullptr, 0, M, D, stream));
-    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    STACK_TRY(stllm_rmsnorm(adt, a->x, a->ldx, w.ln1, a->eps, h, D, nullptr, 0, M, D, stream));
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv;
     g.aux0 = a->rope_cos; g.aux1 = a->rope_sin; g.rope_seq = a->S; g.rope_cols = 2 * D; g.M = M; g.N = 3 * D; g.K = D; g.ldo = 3 * D;
     char* qkv = qkv_s;
@@ -168,18 +183,18 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
     g.out = qkv;
     STACK_TRY(stllm_gemm(&g, stream));
     const int64_t rs = 3 * D;
-    STACK_TRY(stllm_attention(a->dtype, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
+    STACK_TRY(stllm_attention(adt, qkv, bs, rs, qkv + (int64_t)D * e, bs, rs, qkv + (int64_t)2 * D * e, bs, rs, att,
                               (int64_t)a->S * D, D, a->B, a->n_heads, a->S, a->S, hd, scale, 1, a->kv_len, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wo; g.ldw = w.ld_o;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
-    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln2, a->eps, h, D, nullptr, 0, M, D, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    STACK_TRY(stllm_rmsnorm(adt, a->x, a->ldx, w.ln2, a->eps, h, D, nullptr, 0, M, D, stream));
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = D; g.W = w.wgu; g.ldw = w.ld_gu;
     g.out = gu; g.ldo = a->inter; g.M = M; g.N = 2 * a->inter; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
-    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes);
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_RESID; g.A = gu; g.lda = a->inter; g.W = w.wdown; g.ldw = w.ld_down;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->inter;
     STACK_TRY(stllm_gemm(&g, stream));

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 import torch
 
-BF16, F16, F32 = 0, 1, 2
+BF16, F16, F32, BF16X3 = 0, 1, 2, 3   # BF16X3: stllm_gemm / the stack entry points only (fp32 activations, split bf16 weights)
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_ROPE, EPI_PATCH = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
@@ -25,7 +25,7 @@ EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
            "stllm_attention_decode", "stllm_gemm_profile", "stllm_gemm_profile_count", "stllm_gemm_profile_read",
            "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers",
-           "stllm_gemm_fold_supported", "stllm_row_stats"]
+           "stllm_split3_rows", "stllm_gemm_split_ws_bytes"]
 
 
 def torch_dtype(d):
@@ -47,8 +47,7 @@ class GemmArgs(ctypes.Structure):
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float),
-                ("fold_out_t", c_void_p), ("fold_ldo_t", c_int64), ("fold_stats_out", c_void_p),
-                ("fold_stats_in", c_void_p), ("fold_groups", c_int), ("fold_eps", ctypes.c_float), ("fold_colsum", c_void_p)]
+                ("split_ws", c_void_p), ("split_ws_bytes", c_int64)]
 
 
 class VitBlockWeights(ctypes.Structure):
@@ -57,15 +56,13 @@ class VitBlockWeights(ctypes.Structure):
                 ("wproj", c_void_p), ("ld_proj", c_int64), ("bproj", c_void_p),
                 ("n2w", c_void_p), ("n2b", c_void_p), ("e2", c_float),
                 ("wfc1", c_void_p), ("ld_fc1", c_int64), ("bfc1", c_void_p),
-                ("wfc2", c_void_p), ("ld_fc2", c_int64), ("bfc2", c_void_p),
-                ("wqkv_f", c_void_p), ("bqkv_f", c_void_p), ("cs_qkv", c_void_p),
-                ("wfc1_f", c_void_p), ("bfc1_f", c_void_p), ("cs_fc1", c_void_p)]
+                ("wfc2", c_void_p), ("ld_fc2", c_int64), ("bfc2", c_void_p)]
 
 
 class VitBlocksArgs(ctypes.Structure):
     _fields_ = [("dtype", c_int), ("n_seq", c_int), ("seq_len", c_int), ("num_heads", c_int), ("dim", c_int), ("hidden", c_int),
                 ("x", c_void_p), ("ldx", c_int64), ("scratch", c_void_p), ("scratch_bytes", c_int64),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("fold_norms", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
 class LlamaLayerWeights(ctypes.Structure):
@@ -124,8 +121,8 @@ def _bind(L, strict=True):
     B("stllm_gemm_profile", [c_int, c_char_p])
     B("stllm_gemm_profile_count", [])
     B("stllm_gemm_profile_read", [c_int, c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)])
-    B("stllm_gemm_fold_supported", [c_int] * 5)
-    B("stllm_row_stats", [c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p])
+    B("stllm_split3_rows", [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p])
+    B("stllm_gemm_split_ws_bytes", [c_int] * 4, c_int64)
     B("stllm_vit_blocks_scratch_bytes", [c_int] * 5, c_int64)
     B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
     B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
@@ -401,14 +398,21 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None, a_norm=None, fold_out=None, fold_in=None):
+         a_rows=None, o_rows=None, a_norm=None):
     """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
+    dtype fp32 with a bf16 weight of 3 K columns (pack.split3_weight: the runtime's "bf16x3" mode) selects STLLM_BF16X3: a and every output
+    stay fp32, the product runs as three bf16 matrix-core passes (stllm_hip.h).
     a_norm=(x, gamma, eps) with a=None (decode regime, M <= 8, 16-bit dtypes): the A operand is RMSNorm(x) * gamma of the fp32
     rows x [M,K], computed inside the kernel (stllm_hip.h: a_norm_*)."""
     td = torch_dtype(dtype)
     args = GemmArgs()
     args.dtype, args.epilogue, args.act, args.out_is_f32 = dtype_code(td), epilogue, act, int(out_f32)
-    _req(w, td, "W")
+    split = td == torch.float32 and w.dtype == torch.bfloat16 and epilogue != EPI_PATCH and a_norm is None
+    if split:
+        _req(w, torch.bfloat16, "W (bf16x3)")
+        args.dtype, out_f32 = BF16X3, True
+    else:
+        _req(w, td, "W")
     N = w.shape[0]
     if epilogue == EPI_PATCH:
         M, K = n_frames * 256, 588
@@ -456,40 +460,46 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         args.o_rows_per_batch, args.o_batch_stride = o_rows
     args.out, args.ldo = _p(out), out.stride(-2)
     args.M, args.N, args.K = M, N, K
-    if fold_out is not None:   # producer half of the folded LayerNorm: (out_t [M, N] compute dtype, stats f32 [M, N / 64, 2])
-        ot, st = fold_out
-        _req(ot, td, "fold out_t"); _req(st, torch.float32, "fold stats")
-        args.fold_out_t, args.fold_ldo_t, args.fold_stats_out = _p(ot), ot.stride(-2), _p(st)
-    if fold_in is not None:    # consumer half: (stats f32 [M, K / 64, 2], eps, colsum f32 [N]); w = gamma (.) W, bias = W beta + b
-        st, eps, cs = fold_in
-        _req(st, torch.float32, "fold stats"); _req(cs, torch.float32, "fold colsum")
-        args.fold_stats_in, args.fold_groups, args.fold_eps, args.fold_colsum = _p(st), K // 64, float(eps), _p(cs)
+    if split:
+        if w.shape[1] != 3 * K:
+            raise RuntimeError(f"gemm(bf16x3): the split weight must have 3 K = {3 * K} columns, got {w.shape[1]}")
+        need = int(lib().stllm_gemm_split_ws_bytes(M, N, K, epilogue))
+        sws = split_workspace(w.device, need)
+        args.split_ws, args.split_ws_bytes = _p(sws), sws.numel()
     ws = gemm_workspace(w.device)
     args.workspace, args.workspace_bytes = _p(ws), ws.numel()
     _check(lib().stllm_gemm(ctypes.byref(args), _stream()), "stllm_gemm")
     return out
 
 
-# 1: stllm_vit_blocks runs the ViT's LayerNorms FOLDED into the qkv / fc1 GEMMs (stllm_hip.h fold_*).  Built, parity-green and OFF by default:
-# on MI355X the folded step measures +0.3 ms (the two consumer epilogues cost +6-7 us per tile, the producers +3.8 us per launch, against
-# 23 us of LayerNorm kernels + boundaries saved per layer; profiles/r03_ln_fold.md)
-LN_FOLD = os.environ.get("STLLM_LN_FOLD", "0") == "1"
+def stack_dtype_code(td, w):
+    """dtype code of a whole-stack entry point: fp32 activations over split bf16 weights = the bf16x3 mode"""
+    return BF16X3 if (td == torch.float32 and w.dtype == torch.bfloat16) else dtype_code(td)
 
 
-def gemm_fold_supported(dtype, M, D, n_out, gelu=False):
-    return bool(lib().stllm_gemm_fold_supported(dtype_code(torch_dtype(dtype)), M, D, n_out, int(gelu)))
-
-
-def row_stats(x, dtype):
-    """x f32 [M, D] -> (T(x) [M, D], partial (sum, sum of squares) per 64-column group f32 [M, D / 64, 2]) — the producer half of the folded
-    LayerNorm for a stream no GEMM has written yet (stllm_hip.h: stllm_row_stats)"""
+def split3(x, weight_side=False, out=None):
+    """x f32 [M, K] -> bf16 [M, 3 K]: (hi | hi | lo) for the A operand, (hi | lo | hi) for a weight (stllm_split3_rows)."""
     _req(x, torch.float32, "x")
-    td = torch_dtype(dtype)
-    M, D = x.shape
-    out_t = torch.empty((M, D), device=x.device, dtype=td)
-    stats = torch.empty((M, D // 64, 2), device=x.device, dtype=torch.float32)
-    _check(lib().stllm_row_stats(dtype_code(td), _p(x), x.stride(0), _p(out_t), out_t.stride(0), _p(stats), M, D, _stream()), "stllm_row_stats")
-    return out_t, stats
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, 3 * K), device=x.device, dtype=torch.bfloat16)
+    _req(out, torch.bfloat16, "out")
+    _check(lib().stllm_split3_rows(_p(x), x.stride(0), 0, 0, _p(out), out.stride(0), M, K, int(bool(weight_side)), _stream()), "stllm_split3_rows")
+    return out
+
+
+_split_ws = {}
+
+
+def split_workspace(device, nbytes):
+    """scratch of the bf16x3 GEMMs (the split A operand; SwiGLU: + the fp32 gate/up columns), one per (device, stream) like the GEMM
+    workspace: grows, never shrinks (a replaced buffer stays alive until the launches that use it have run: torch's stream-ordered allocator)"""
+    key = str(torch.device(device)) if torch.device(device).type != "cuda" else (_dev_index(device), int(torch.cuda.current_stream(_dev_index(device)).cuda_stream))
+    buf = _split_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _split_ws[key] = buf
+    return buf
 
 
 def vit_block_array(blocks):
@@ -503,9 +513,6 @@ def vit_block_array(blocks):
         w.n2w, w.n2b, w.e2 = pk["n2w"].data_ptr(), pk["n2b"].data_ptr(), float(pk["e2"])
         w.wfc1, w.ld_fc1, w.bfc1 = pk["wfc1"].data_ptr(), pk["wfc1"].stride(0), pk["bfc1"].data_ptr()
         w.wfc2, w.ld_fc2, w.bfc2 = pk["wfc2"].data_ptr(), pk["wfc2"].stride(0), pk["bfc2"].data_ptr()
-        if "wqkv_f" in pk:   # LayerNorms folded into qkv / fc1 (pack.fold_layernorm): 16-bit dtypes
-            w.wqkv_f, w.bqkv_f, w.cs_qkv = pk["wqkv_f"].data_ptr(), pk["bqkv_f"].data_ptr(), pk["cs_qkv"].data_ptr()
-            w.wfc1_f, w.bfc1_f, w.cs_fc1 = pk["wfc1_f"].data_ptr(), pk["bfc1_f"].data_ptr(), pk["cs_fc1"].data_ptr()
     return arr
 
 
@@ -516,11 +523,12 @@ def vit_blocks(x, blocks, carr, *, n_seq, seq_len, num_heads, dtype):
     td = torch_dtype(dtype)
     dim, hidden = x.shape[1], blocks[0]["wfc1"].shape[0]
     L = lib()
-    need = int(L.stllm_vit_blocks_scratch_bytes(dtype_code(td), n_seq, seq_len, dim, hidden))
+    code = stack_dtype_code(td, blocks[0]["wfc1"])
+    need = int(L.stllm_vit_blocks_scratch_bytes(code, n_seq, seq_len, dim, hidden))
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
     ws = gemm_workspace(x.device)
-    a = VitBlocksArgs(dtype_code(td), n_seq, seq_len, num_heads, dim, hidden, x.data_ptr(), x.stride(0), scratch.data_ptr(), need,
-                      ws.data_ptr(), ws.numel(), int(LN_FOLD))
+    a = VitBlocksArgs(code, n_seq, seq_len, num_heads, dim, hidden, x.data_ptr(), x.stride(0), scratch.data_ptr(), need,
+                      ws.data_ptr(), ws.numel())
     _check(L.stllm_vit_blocks(ctypes.byref(a), carr, len(blocks), _stream()), "stllm_vit_blocks")
     return x
 
@@ -542,16 +550,17 @@ def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=Non
     carr = llama_layer_array(layers, cache)."""
     _req(x, torch.float32, "x")
     td = torch_dtype(dtype)
-    hidden, inter = x.shape[1], layers[0]["wdown"].shape[1]
+    hidden, inter = x.shape[1], layers[0]["wgu"].shape[0] // 2
     L = lib()
-    need = int(L.stllm_llama_layers_scratch_bytes(dtype_code(td), B, S, hidden, inter))
+    code = stack_dtype_code(td, layers[0]["wdown"])
+    need = int(L.stllm_llama_layers_scratch_bytes(code, B, S, hidden, inter))
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
     ws = gemm_workspace(x.device)
     cos, sin = rope
     _req(cos, torch.float32, "rope cos"); _req(sin, torch.float32, "rope sin")
     if kv_len is not None:
         _req(kv_len, torch.int32, "kv_len")
-    a = LlamaLayersArgs(dtype_code(td), B, S, n_heads, hidden, inter, float(eps), x.data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(),
+    a = LlamaLayersArgs(code, B, S, n_heads, hidden, inter, float(eps), x.data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(),
                         _p(kv_len), cache.max_len if cache is not None else 0, scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
     _check(L.stllm_llama_layers(ctypes.byref(a), carr, len(layers), _stream()), "stllm_llama_layers")
     return x

@@ -47,14 +47,6 @@ class Block(nn.Module):
 
     def pack(self, dtype):
         a, m = self.attn, self.mlp
-        pk = self._pack_plain(dtype)
-        if hip.torch_dtype(dtype) != torch.float32:   # norm1 / norm2 folded into qkv / fc1 (stllm_vit_blocks, 16-bit modes)
-            pk["wqkv_f"], pk["bqkv_f"], pk["cs_qkv"] = pack.fold_layernorm(a.qkv.weight, pk["bqkv"], self.norm1.weight, self.norm1.bias, dtype)
-            pk["wfc1_f"], pk["bfc1_f"], pk["cs_fc1"] = pack.fold_layernorm(m.fc1.weight, m.fc1.bias, self.norm2.weight, self.norm2.bias, dtype)
-        return pk
-
-    def _pack_plain(self, dtype):
-        a, m = self.attn, self.mlp
         return dict(n1w=self.norm1.weight, n1b=self.norm1.bias, e1=self.norm1.eps,
                     wqkv=pack.linear(a.qkv.weight, dtype), bqkv=pack.vit_qkv_bias(a.q_bias, a.v_bias),
                     wproj=pack.linear(a.proj.weight, dtype), bproj=pack.f32(a.proj.bias),

@@ -22,7 +22,7 @@ def params_fingerprint(params):
     for p in params:
         v += p._version
         a ^= p.data_ptr()
-    return (v, a)
+    return (v, a, runtime.gemm_split())   # the "bf16x3" mode shares torch.float32 with the plain verify mode but packs split weights
 
 
 class Linear(nn.Module):
@@ -38,7 +38,7 @@ class Linear(nn.Module):
 
     def packed(self, dtype):
         key = hip.torch_dtype(dtype)
-        ver = (self.weight._version, self.weight.data_ptr())
+        ver = (self.weight._version, self.weight.data_ptr(), runtime.gemm_split())
         hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
             hit = (ver, pack.linear(self.weight, key), pack.f32(self.bias))

@@ -108,16 +108,19 @@ class LlamaModel(nn.Module):
         fp = params_fingerprint(self.layers.parameters())   # a stale packed copy after p.data.copy_ / .to(device) would run silently
         hit = self._packed.get(dt)
         if hit is None or hit[0] != fp:
-            self._packed = {}  # one packed copy at a time (13.5 GB at 7B)
+            self._packed = {}  # one packed copy at a time (13.5 GB at 7B) ...
+            self._carr = {}    # ... including the C-side table, which holds a reference to the list it was built from
             hit = (fp, [l.pack(dt, self.config.num_attention_heads) for l in self.layers])
             self._packed[dt] = hit
         return hit[1]
 
     def repack(self):
         self._packed = {}
+        self._carr = {}
 
     def _load_from_state_dict(self, *a, **k):
         self._packed = {}
+        self._carr = {}
         return super()._load_from_state_dict(*a, **k)
 
     def rope(self, S, device):
@@ -271,7 +274,7 @@ class LlamaForCausalLM(nn.Module):
         self._lm_packed = {}
 
     def lm_weight(self, dt):
-        ver = (self.lm_head.weight._version, self.lm_head.weight.data_ptr())
+        ver = (self.lm_head.weight._version, self.lm_head.weight.data_ptr(), runtime.gemm_split())
         hit = self._lm_packed.get(dt)
         if hit is None or hit[0] != ver:
             hit = (ver, pack.pad_rows(pack.linear(self.lm_head.weight, dt), 128))

@@ -164,7 +164,7 @@ class STLLMModel(Blip2Base):
                 s0, e0 = parallel.frame_range(frames.shape[0], rank, world, load)
                 tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, 32, 4096), dtype=torch.float32, device=image.device)
             else:
-                tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load)
+                tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load, simulate=getattr(self, "_fp_sim_tokens", None))
             if getattr(self, "_fp_keep_tokens", False):   # bench.py's one-off check of the gathered block against a single-GPU encode
                 self._fp_last_tokens = tokens
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
@@ -527,7 +527,9 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
         if loss_pretrain is not None:
             loss = loss + loss_pretrain
         hip.gemm_workspace_check(logits.device) if logits.is_cuda else None   # non-blocking (see hip.gemm_workspace_check)
-        return Output(loss=loss, logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
+        res = Output(loss=loss, logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
+        object.__setattr__(res, "loss_mvm", loss_pretrain)   # not a key (integer indexing stays HF's): the MVM term on its own, for tests / logging
+        return res
 
     @torch.no_grad()
     def generate(self, inputs_embeds=None, max_new_tokens=16, num_beams=1, do_sample=False, stopping_criteria=None,

@@ -17,27 +17,28 @@ parameter lives on); none changes the mathematical function:
 """
 import torch
 
+from . import runtime
 from .hip import torch_dtype
 
 
+def split3_weight(w):
+    """fp32 [N, K] -> bf16 [N, 3 K] = (hi | lo | hi) along K, hi = bf16(w), lo = bf16(w - hi): the weight operand of the "bf16x3" GEMMs
+    (stllm_hip.h STLLM_BF16X3; the same rounding as stllm_split3_rows side 1)."""
+    wf = w.detach().float()
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    return torch.cat((hi, lo, hi), dim=1).contiguous()
+
+
 def _cast(w, dtype):
-    return w.detach().to(torch_dtype(dtype)).contiguous()
+    td = torch_dtype(dtype)
+    if td == torch.float32 and runtime.gemm_split() and w.dim() == 2 and w.shape[1] % 64 == 0:
+        return split3_weight(w)
+    return w.detach().to(td).contiguous()
 
 
 def linear(w, dtype):
     return _cast(w, dtype)
-
-
-def fold_layernorm(w, bias, gamma, beta, dtype):
-    """LayerNorm folded into the Linear that follows it (stllm_hip.h fold_*): y = LN(x) W^T + b = rstd (x - mean) (gamma (.) W)^T + (W beta + b).
-    Returns (W' = gamma (.) W in `dtype`, bias' = W beta + b in fp32, colsum[n] = sum_k W'[n, k] of the ROUNDED W' in fp32 — the term the
-    consumer epilogue multiplies with -rstd * mean must match what the MFMAs actually summed)."""
-    wf = w.detach().float()
-    wq = (wf * gamma.detach().float()[None, :]).to(torch_dtype(dtype)).contiguous()
-    b = wf @ beta.detach().float()
-    if bias is not None:
-        b = b + bias.detach().float()
-    return wq, b.contiguous(), wq.float().sum(dim=1).contiguous()
 
 
 def f32(b):
@@ -75,9 +76,10 @@ def llama_qkv(wq, wk, wv, dtype, n_heads=32):
 def llama_gate_up(wg, wu, dtype):
     n, k = wg.shape
     assert n % 32 == 0
-    g = _cast(wg, dtype).view(n // 32, 32, k)
-    u = _cast(wu, dtype).view(n // 32, 32, k)
-    return torch.stack((g, u), dim=1).reshape(2 * n, k).contiguous()
+    g = _cast(wg, dtype)
+    u = _cast(wu, dtype)
+    k = g.shape[1]   # 3 K in the split mode
+    return torch.stack((g.view(n // 32, 32, k), u.view(n // 32, 32, k)), dim=1).reshape(2 * n, k).contiguous()
 
 
 def bert_qkv(q, k, v, dtype):

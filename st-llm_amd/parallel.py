@@ -92,14 +92,21 @@ def all_gather_frames(local, n_frames, rank, world, group=None, extra=None):
     return torch.cat([out[r * mx: r * mx + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0)
 
 
-def encode_frames_parallel(encode_fn, frames, rank, world, group=None, token_shape=(32, 4096), extra=None):
+def encode_frames_parallel(encode_fn, frames, rank, world, group=None, token_shape=(32, 4096), extra=None, simulate=None):
     """frames: [N, 3, 224, 224] (the full batch, or anything indexable by the frame range);
     encode_fn(frames_slice) -> tokens [n, 32, D] fp32.  Returns tokens of all N frames on every rank.
-    extra: see frame_counts (prefill load of every rank in frame units)."""
+    extra: see frame_counts (prefill load of every rank in frame units).
+    simulate: a pre-computed token block [N, 32, D] standing in for the peers' ranges — ONE process measuring rank `rank`'s share of a
+    `world`-rank step without a process group (bench.py's frame_parallel_projection): the collective becomes a device copy of the block
+    with this rank's own tokens written into their range."""
     n = frames.shape[0]
     s, e = frame_range(n, rank, world, extra)
     if e > s:
         local = encode_fn(frames[s:e])
     else:  # more ranks than frames: this rank only takes part in the collective
         local = torch.zeros((0,) + tuple(token_shape), dtype=torch.float32, device=frames.device)
+    if simulate is not None:
+        out = simulate.clone()
+        out[s:e] = local
+        return out
     return all_gather_frames(local, n, rank, world, group, extra)

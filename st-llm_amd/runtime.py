@@ -1,9 +1,13 @@
 """Process-wide numerics mode of the HIP path.
 
-  "bf16" — MFMA bf16 inputs / fp32 accumulate, fp32 residual stream + norm/softmax statistics (default,
-           BASELINE.json config 2)
-  "fp16" — same with fp16 MFMA inputs (the reference's own production dtype: demo.py:46, blip2.py:36)
-  "fp32" — exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the "verify" mode that meets the <=1e-2 logits bar
+  "bf16"   — MFMA bf16 inputs / fp32 accumulate, fp32 residual stream + norm/softmax statistics (default,
+             BASELINE.json config 2)
+  "fp16"   — same with fp16 MFMA inputs (the reference's own production dtype: demo.py:46, blip2.py:36)
+  "fp32"   — exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the "verify" mode that meets the <=1e-2 logits bar
+  "bf16x3" — the SPLIT verify mode (round 4): activations, norms, softmax and attention as in "fp32", every Linear as three bf16
+             matrix-core products of split operands (x = hi + lo; stllm_hip.h STLLM_BF16X3): the fp32 accuracy class at ~3x the
+             bf16 GEMM time instead of 16x.  compute_dtype() is torch.float32 in this mode; gemm_split() tells the packers to
+             store the weights split.
 """
 import contextlib
 
@@ -11,22 +15,37 @@ import torch
 
 from .hip import torch_dtype
 
-_state = {"dtype": torch.bfloat16}
+_state = {"dtype": torch.bfloat16, "split": False}
+SPLIT_NAMES = ("bf16x3", "split")
 
 
 def set_compute_dtype(d):
-    _state["dtype"] = torch_dtype(d)
+    if isinstance(d, str) and d in SPLIT_NAMES:
+        _state.update(dtype=torch.float32, split=True)
+    else:
+        _state.update(dtype=torch_dtype(d), split=False)
 
 
 def compute_dtype():
     return _state["dtype"]
 
 
+def gemm_split():
+    """True in the "bf16x3" mode: pack.* store GEMM weights as split bf16 [N, 3 K] and hip.gemm runs them as STLLM_BF16X3"""
+    return _state["split"]
+
+
+def mode_name():
+    if _state["split"]:
+        return "bf16x3"
+    return {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "fp32"}[_state["dtype"]]
+
+
 @contextlib.contextmanager
 def use_dtype(d):
-    old = _state["dtype"]
+    old = dict(_state)
     set_compute_dtype(d)
     try:
         yield
     finally:
-        _state["dtype"] = old
+        _state.update(old)

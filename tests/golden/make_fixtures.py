@@ -514,10 +514,65 @@ def fx_c2_full():
          ref_forward_seconds=np.array([time.time() - t1]))
 
 
+
+def fx_stllm_flagship():
+    """The reference's flagship SHIPPED combination (config/instructblipbase_stllm_conversation.yaml:11,14-17): text-conditioned Q-Former +
+    global-local 'residual' pooling + dynamic masking over the pooled R*32 block + the MVM branch, whose slices start at img_start = 0
+    (st_llm.py:71: BOS and the 'before' ids are inside the slice — a quirk of the reference that a drop-in must reproduce)."""
+    fx_stllm("stllm_flagship", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="",
+                                    video_input="residual", residual_size=4, use_mask=True, mvm_decode=True,
+                                    qformer_text_input=True, max_txt_len=32, end_sym=" 2", vit_precision="fp32"), Tn=8)
+
+
+FULL_CFGS = {
+    # BASELINE configs[2] (config/instructblipbase_stllm_conversation.yaml:11,14-15,21 without the mask: bench.py's c3 leg): B=4 x T=64, text Q-Former, residual R=16
+    "c3": (dict(vit_model="eva_clip_g", video_input="residual", residual_size=16, use_mask=False, mvm_decode=False, qformer_text_input=True,
+                max_txt_len=64), 4, 64, True),
+    # BASELINE configs[3]: dynamic masking + MVM forward at T=32 ('all' pooling: L=1024 visual tokens, two prefills S ~ 560 + 1100; st_llm.py:56-92, 480-493)
+    "c4": (dict(vit_model="eva_clip_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False, max_txt_len=32), 1, 32, False),
+    # BASELINE configs[4] (config/minigpt4base_stllm_qa.yaml:3,7,11,13-14): BT-Adapter backbone, 'all', mask + MVM, T=16
+    "c5": (dict(vit_model="eva_btadapter_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False, max_txt_len=32), 1, 16, False),
+}
+MASK_SEED = 1234   # numpy's global RNG before the reference's forward: st_llm.py:482-484 draws the rate and the shuffles from it
+
+
+def fx_full(tag):
+    """BASELINE configs[2..4] at FULL SIZE (39 + 12 + 32 layers) through the reference's own forward on CPU (fp32) on exactly the samples
+    bench.py --config <tag> times (bench.make_samples + bench.CONFIGS).  Same logits summary as c2_full, per clip; the mask the reference
+    drew (numpy global RNG seeded with MASK_SEED) is stored so that the device path can be given the same one."""
+    import bench
+    t0 = time.time()
+    mcfg, B, Tn, text = FULL_CFGS[tag]
+    cfg = _Cfg(dict(dict(image_size=224, num_query_token=32, llama_model="", end_sym=" 2", vit_precision="fp32"), **mcfg))
+    model = _build_ref_stllm(cfg, 39, 12, 32)
+    print("built", time.time() - t0, flush=True)
+    fill_stllm(model)
+    print("filled", time.time() - t0, flush=True)
+    samples = bench.make_samples(B, Tn, "cpu", text=text)
+    sm = model.model.stllm_model
+    np.random.seed(MASK_SEED)
+    t1 = time.time()
+    out = model(samples=samples)
+    dt = time.time() - t1
+    print("forward", dt, flush=True)
+    extra = {}
+    if cfg.get("use_mask", False):
+        extra["mask"] = sm.mask.squeeze(1).numpy()
+        extra["img_len"] = np.array([sm.img_len, sm.mask_img_len])
+        np.random.seed(MASK_SEED)
+        _, loss_mvm, _ = model.model(samples)          # the MVM term on its own (second full forward)
+        extra["loss_mvm"] = np.array([loss_mvm.item()])
+    lg = out.logits
+    top = lg.topk(5, dim=-1)
+    save(f"{tag}_full", logits_slice=lg[:, ::3, ::499].numpy(), logits_stats=stats(lg), seq_len=np.array([lg.shape[1]]),
+         top_ids=top.indices.numpy(), top_vals=top.values.numpy(), row_norms=lg.norm(dim=-1).numpy(),
+         loss=np.array([out.loss.item()]), ref_forward_seconds=np.array([dt]), **extra)
+
+
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
            stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip,
-           btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward, pos_embed=fx_pos_embed)
-SLOW = dict(c1_full=fx_c1_full, c2_full=fx_c2_full)
+           stllm_flagship=fx_stllm_flagship, btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward, pos_embed=fx_pos_embed)
+SLOW = dict(c1_full=fx_c1_full, c2_full=fx_c2_full, c3_full=lambda: fx_full("c3"), c4_full=lambda: fx_full("c4"), c5_full=lambda: fx_full("c5"))
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "st-llm_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip", "preprocess.hip", "gemm.hip"]
+KERNEL_SOURCES = ["train_ops.hip", "attention_bwd.hip", "attention.hip", "gemv.hip", "norm.hip", "elementwise.hip", "split3.hip", "preprocess.hip", "gemm.hip"]
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; }}\n"   # 160 KB of dynamic LDS
 

@@ -11,6 +11,5 @@ int stllm_gemm_w4_launch_f16(int, int, const sg::GemmParams&, hipStream_t) { ret
 float stllm_gemm_w4_estimate_us(int, int, int, int, int* shape, int* split) { if (shape) *shape = 44; if (split) *split = 1; return 1.0e30f; }
 // profile.cpp (HIP events) is not part of the emulated library either
 int stllm_prof_begin(const stllm_gemm_args*, void*) { return -1; }
-void stllm_prof_end(int, const stllm_gemm_args*, void*) {}
-int stllm_gemm_w4_fold_consumer_shape(int, int, int, int) { return 0; }
+void stllm_prof_end(int, int, const stllm_gemm_args*, void*) {}
 extern "C" int stllm_gemm_w4_plan(int, int, int, int, int, int*) { return STLLM_ERR_UNSUPPORTED; }

@@ -31,7 +31,7 @@ def test_abi_exports_match_header():
     for name in sorted(declared):
         assert hasattr(L, name), f"libstllm_hip.so does not export {name}"
     assert set(hip.EXPORTS) == declared, (set(hip.EXPORTS) ^ declared)
-    assert L.stllm_abi_version() == 4
+    assert L.stllm_abi_version() == 5
 
 
 def test_phased_gemm_schedule_invariants():
@@ -186,7 +186,7 @@ def _emulate_gather(vis_flat, table, rows):
     return out
 
 
-@pytest.mark.parametrize("name,text,use_mask", [("stllm_minigpt4", False, True), ("stllm_instructblip", True, False)])
+@pytest.mark.parametrize("name,text,use_mask", [("stllm_minigpt4", False, True), ("stllm_instructblip", True, False), ("stllm_flagship", True, True)])
 def test_assembly_index_tables_vs_oracle(name, text, use_mask):
     """STLLMModel._assemble (host) + an emulated gather == oracle.assemble == the reference's attention_mask/targets."""
     from stllm_amd.models import st_llm

@@ -476,6 +476,52 @@ def test_emulated_tile_gemm_epilogues(dtype):
 
 
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
+def test_emulated_bf16x3_gemm_every_epilogue():
+    """STLLM_BF16X3 (round 4, the split verify mode) through the REAL stllm_gemm entry point on the emulated library: fp32 A split on the fly
+    into (hi | hi | lo), weight packed (hi | lo | hi), ONE bf16 GEMM with K' = 3 K and fp32 output, fp32 post-epilogues — against fp64.
+    The bound is the fp32 accuracy class (the bf16 GEMM of the same operands is off by ~2^-8)."""
+    from stllm_amd import pack
+    M, N, K = 70, 256, 128
+    a = rnd(M, K, seed=190, scale=0.5)
+    w = rnd(N, K, seed=191, scale=0.1)
+    bias, resid = rnd(N, seed=192), rnd(M, N, seed=193)
+    cos, sin = pack.rope_tables(35, 128)
+    big = rnd(2 * 50, K, seed=194, scale=0.5)
+    w3 = pack.split3_weight(w)
+    assert w3.shape == (N, 3 * K) and w3.dtype == torch.bfloat16
+    hi, lo = w3[:, :K].float(), w3[:, K:2 * K].float()
+    assert torch.equal(w3[:, 2 * K:], w3[:, :K]) and float((hi + lo - w).abs().max()) <= 2.0 ** -16 * float(w.abs().max())
+    f32 = torch.float32
+    want = {
+        "store_bias_gelu": C.gemm(a, w, dtype=f32, bias=bias, act=C.ACT_GELU),
+        "store": C.gemm(a, w, dtype=f32, out_f32=True),
+        "resid": C.gemm(a, w, dtype=f32, epilogue=C.EPI_RESID, bias=bias, resid=resid.clone()),
+        "swiglu": C.gemm(a, w, dtype=f32, epilogue=C.EPI_SWIGLU),
+        "rope": C.gemm(a, w, dtype=f32, epilogue=C.EPI_ROPE, rope=(cos, sin), rope_seq=35, rope_cols=128),
+        "rows2": C.gemm(big, w, dtype=f32, epilogue=C.EPI_RESID, resid=resid.clone(), out=torch.zeros(2 * 40, N), M=70, a_rows=(35, 50 * K),
+                        o_rows=(35, 40 * N)),
+    }
+    with _hipemu.emulated() as hip:
+        with pytest.raises(RuntimeError, match="3 K"):
+            hip.gemm(a, w3[:, :2 * K].contiguous(), dtype=f32)
+        got = {
+            "store_bias_gelu": hip.gemm(a, w3, dtype=f32, bias=bias, act=C.ACT_GELU),
+            "store": hip.gemm(a, w3, dtype=f32),
+            "resid": hip.gemm(a, w3, dtype=f32, epilogue=C.EPI_RESID, bias=bias, resid=resid.clone()),
+            "swiglu": hip.gemm(a, w3, dtype=f32, epilogue=C.EPI_SWIGLU),
+            "rope": hip.gemm(a, w3, dtype=f32, epilogue=C.EPI_ROPE, rope=(cos, sin), rope_seq=35, rope_cols=128),
+            "rows2": hip.gemm(big, w3, dtype=f32, epilogue=C.EPI_RESID, resid=resid.clone(), out=torch.zeros(2 * 40, N), M=70, a_rows=(35, 50 * K),
+                              o_rows=(35, 40 * N)),
+        }
+        a3 = hip.split3(a)
+    assert torch.equal(a3[:, :K], a3[:, K:2 * K]) and torch.equal(a3[:, :K], a.to(torch.bfloat16))
+    assert torch.equal(a3[:, 2 * K:], (a - a.to(torch.bfloat16).float()).to(torch.bfloat16))
+    for n in want:
+        assert got[n].dtype == torch.float32
+        close(got[n], want[n], 2e-5, f"bf16x3 gemm {n}")
+
+
+@pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
 def test_emulated_patch_embed_gemm():
     from stllm_amd import pack
     frames = rnd(1, 3, 224, 224, seed=95)

@@ -158,6 +158,15 @@ def test_stllm_instructblip_style():
     _e2e("stllm_instructblip", CFG_INSTRUCTBLIP, 8, True)
 
 
+CFG_FLAGSHIP = dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=True, mvm_decode=True, qformer_text_input=True)
+
+
+def test_stllm_flagship_yaml_combination():
+    """config/instructblipbase_stllm_conversation.yaml:11,14-17: text Q-Former + residual pooling + mask over the pooled block + MVM with
+    img_start = 0 (st_llm.py:71) — the oracle against the reference's own forward (loss AND loss_mvm)."""
+    _e2e("stllm_flagship", CFG_FLAGSHIP, 8, True)
+
+
 def test_chat_upload_video_path():
     g = golden("chat")
     sd = sd_from({**shapes.stllm_model_shapes(2, 2, True, "residual", False, qf_vocab=32000), **shapes.llama_shapes(2)})
