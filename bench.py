@@ -78,6 +78,13 @@ def build_model(device, args, model_cfg=None):
                mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2",
                llama_model=dict(num_hidden_layers=args.llm_layers))
     cfg.update(model_cfg or {})
+    if cfg.get("qformer_text_input"):
+        # text-conditioned configs (c3): the token-id conventions of the fixture generator's fake tokenizers (tests/golden/ref_shim.py: BERT side
+        # bos id 1 in a 32000-word table, no '[PAD]' growth of the Llama vocabulary), so that bench.py's c3 inputs are exactly what the
+        # reference ran for tests/golden/c3_full.npz; the workload's sizes do not change (32000 instead of 32001 lm_head rows)
+        from stllm_amd.tokenizer import IdTokenizer
+        IdTokenizer.hf_special_tokens = False
+        Blip2Base.init_tokenizer = classmethod(lambda cls, truncation_side="right": IdTokenizer(0, 1, 2, 32000))
     model = st_llm.STLLMForCausalLM.from_config(cfg, device=device)
     if getattr(args, "dry_cpu", False):
         # plumbing check on CPU: the values do not matter, the integer-hash generator (bit-identical on CPU and GPU, ~40 s for the

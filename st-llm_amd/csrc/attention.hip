@@ -13,7 +13,8 @@
 //   * O^T columns are queries too, so the online-softmax rescale is an in-lane multiply.
 //   * K tile rows are padded by 16 B and V^T rows by 8 B: conflict-free ds_read_b128 / ds_read_b64.
 //   * head_dim 88 (EVA-CLIP-g) is zero-padded to 96 in LDS/registers only; HBM traffic stays 88.
-// fp32 path ("verify" numerics): exact-fp32 vector kernel, one wave per query row.
+// fp32 path ("verify" numerics): attn_mfma_f32_kernel — the same schedule on exact-fp32 MFMAs (32x32x2) — from 8 query rows on; an
+// exact-fp32 vector kernel, one wave per query row, for the one-row decode step.
 #include <cstdlib>
 #include "common.h"
 
@@ -918,6 +919,183 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnParams p) {
   }
 }
 
+// ---- exact fp32 path on the MATRIX cores (round 4): v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain per output --------------------
+// The one-wave-per-row kernel above re-reads the whole K and V of a head from L2 for every query row (181 KB per ViT row: ~12 GB per
+// layer) and ran at 3.6 % of the fp32 vector peak: 58 of the 117 ms of a split-verify step (profiles/r04_split_step.md).  This kernel is
+// attn_mfma_kernel's schedule in fp32: a wave owns 32 query rows, 32-key tiles of K (row-major) and V^T go through LDS once per
+// WORKGROUP (register-staged one tile ahead), S^T = K Q^T and O^T += V^T P^T are chains of 32x32x2 fp32 MFMAs (K = 2 per instruction:
+// DP / 2 + 16 DP / 32 of them per tile), softmax statistics per lane exactly as in the 16-bit kernels.  A 16-byte LDS read feeds four MFMAs
+// (the k <-> (step, half) slot map only has to agree between the A and the B operand, Elem<float>::mfma).
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_mfma_f32_kernel(const AttnParams p) {
+  constexpr int KS8 = DP / 8;           // 16-byte K fragments per row half-pair: lane half lh holds d = 8 ks + 4 lh .. + 3
+  constexpr int DB = DP / 32;           // 32-row blocks of O^T
+  constexpr int KPITCH = DP * 4 + 16;   // bytes per K row in LDS
+  constexpr int VPITCH = 32 * 4 + 16;   // bytes per V^T row (32 keys) in LDS
+  constexpr int NT = 64 * NW;
+  constexpr int CPR = DP / 4;           // 16-byte chunks per K / V row
+  constexpr int NCH = 32 * CPR;
+  constexpr int CPT = (NCH + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) char k_lds[32 * KPITCH];
+  __shared__ __attribute__((aligned(16))) char v_lds[DP * VPITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_blk0 = blockIdx.x * (32 * NW);
+  const int qrow = q_blk0 + wave * 32 + li;
+  const int D = p.D;
+  const int kvlen = p.kv_len ? min(p.kv_len[b], p.Skv) : p.Skv;
+
+  f32x4 qf[KS8];   // B operand of S^T: Q[q = li][8 ks + 4 lh .. + 3]
+  {
+    const float* qp = reinterpret_cast<const float*>(p.q) + (int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D;
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) {
+      const int d0 = ks * 8 + lh * 4;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      qf[ks] = (qrow < p.Sq && d0 < D) ? *reinterpret_cast<const f32x4*>(qp + d0) : z;   // D % 4 == 0
+    }
+  }
+  f32x16 o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
+  float m_run = kNeg, l_run = 0.0f;
+
+  int kv_end = kvlen;
+  if (p.causal) kv_end = min(kv_end, q_blk0 + 32 * NW);
+  const float* kbase = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.k_bs + (int64_t)h * D;
+  const float* vbase = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.v_bs + (int64_t)h * D;
+  f32x4 kreg[CPT], vreg[CPT];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = tid + c * NT;
+      const int cc = ch >> 5, row = ch & 31;   // consecutive lanes = consecutive keys: conflict-free transposed V writes
+      const int kv = kv0 + row;
+      const bool ok = (ch < NCH) && (kv < p.Skv) && (cc * 4 < D);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      kreg[c] = ok ? *reinterpret_cast<const f32x4*>(kbase + (int64_t)kv * p.k_rs + cc * 4) : z;
+      vreg[c] = ok ? *reinterpret_cast<const f32x4*>(vbase + (int64_t)kv * p.v_rs + cc * 4) : z;
+    }
+  };
+  const int wave_q_last = q_blk0 + wave * 32 + 31;
+  if (kv_end > 0) load_tile(0);
+  for (int kv0 = 0; kv0 < kv_end; kv0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int ch = tid + c * NT;
+      if (ch < NCH) {
+        const int cc = ch >> 5, row = ch & 31;
+        *reinterpret_cast<f32x4*>(k_lds + row * KPITCH + cc * 16) = kreg[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(v_lds + (cc * 4 + e) * VPITCH + row * 4) = vreg[c][e];
+      }
+    }
+    __syncthreads();
+    if (kv0 + 32 < kv_end) load_tile(kv0 + 32);
+    if (p.causal && kv0 > wave_q_last) continue;
+
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS8; ++ks) {
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(k_lds + li * KPITCH + (ks * 2 + lh) * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[ks][e], s, 0, 0, 0);
+    }
+    const bool need_mask = (kv0 + 32 > kvlen) || (p.causal && kv0 + 31 > q_blk0 + wave * 32);
+    if (need_mask) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool dead = (kv >= kvlen) || (p.causal && kv > qrow);
+        s[r] = dead ? kNeg : s[r];
+      }
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * p.scale_log2;
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = exp2f(fmaf(s[r], p.scale_log2, -mc));   // the library exp2f (full fp32 accuracy), not the hardware approximation
+      s[r] = pv;
+      rs += pv;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    if (__any(m_new != m_run)) {
+      const float alpha = exp2f((m_run - m_new) * p.scale_log2);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += rs;
+    // O^T[d][q] += V^T[d][kv] P^T[kv][q]: the lane's score register r is key (r & 3) + 8 (r >> 2) + 4 lh — registers 4 g .. 4 g + 3 are four
+    // consecutive keys 8 g + 4 lh ..: one 16-byte read of the V^T row feeds their four MFMAs
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(v_lds + (i * 32 + li) * VPITCH + (8 * g + 4 * lh) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], s[4 * g + e], o[i], 0, 0, 0);
+      }
+    }
+  }
+  if (qrow < p.Sq) {
+    const float inv = 1.0f / l_run;
+    float* op = reinterpret_cast<float*>(p.o) + (int64_t)b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * D;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = i * 32 + 8 * g + 4 * lh;
+        if (d0 < D) {
+          const f32x4 ov = {o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv, o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv};
+          *reinterpret_cast<f32x4*>(op + d0) = ov;
+        }
+      }
+    }
+  }
+}
+
+template <int DP, int NW>
+int launch_mfma_f32(const AttnParams& p, hipStream_t stream) {
+  dim3 grid((p.Sq + 32 * NW - 1) / (32 * NW), p.H, p.B), block(64 * NW);
+  hipLaunchKernelGGL((attn_mfma_f32_kernel<DP, NW>), grid, block, 0, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention(fp32 mfma)");
+  return STLLM_OK;
+}
+
+// fp32: matrix-core kernel from 8 query rows on (prefill shapes), the vector kernel for the one-row decode step and tiny problems
+int dispatch_f32(const AttnParams& p, hipStream_t stream, int mode) {
+  if (mode != 0 && p.Sq >= 8) {
+    const int nw = p.Sq <= 32 ? 1 : (p.Sq <= 64 ? 2 : 3);
+    if (p.D == 64) return nw == 1 ? launch_mfma_f32<64, 1>(p, stream) : nw == 2 ? launch_mfma_f32<64, 2>(p, stream) : launch_mfma_f32<64, 3>(p, stream);
+    if (p.D == 88) return nw == 1 ? launch_mfma_f32<96, 1>(p, stream) : nw == 2 ? launch_mfma_f32<96, 2>(p, stream) : launch_mfma_f32<96, 3>(p, stream);
+    if (p.D == 128) return nw == 1 ? launch_mfma_f32<128, 1>(p, stream) : nw == 2 ? launch_mfma_f32<128, 2>(p, stream) : launch_mfma_f32<128, 3>(p, stream);
+  }
+  if (p.Skv > kF32MaxKv) {
+    stllm_set_error("stllm_attention(fp32, vector kernel): Skv %d > %d", p.Skv, kF32MaxKv);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  dim3 grid((p.Sq + 3) / 4, p.H, p.B), block(256);
+  hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, stream, p);
+  STLLM_CHECK_LAUNCH("stllm_attention(fp32)");
+  return STLLM_OK;
+}
+
 template <typename T, int DP, int NW>
 int launch_mfma(const AttnParams& p, hipStream_t stream) {
   dim3 grid((p.Sq + 32 * NW - 1) / (32 * NW), p.H, p.B), block(64 * NW);
@@ -1175,13 +1353,7 @@ extern "C" int stllm_attention(int dtype, const void* q, int64_t q_bs, int64_t q
   switch (dtype) {
     case STLLM_BF16: return dispatch<bf16_t>(p, stream);
     case STLLM_F16: return dispatch<f16_t>(p, stream);
-    case STLLM_F32: {
-      STLLM_CHECK_ARG(Skv <= kF32MaxKv, "stllm_attention(fp32): Skv %d > %d", Skv, kF32MaxKv);
-      dim3 grid((Sq + 3) / 4, H, B), block(256);
-      hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, stream, p);
-      STLLM_CHECK_LAUNCH("stllm_attention(fp32)");
-      return STLLM_OK;
-    }
+    case STLLM_F32: return dispatch_f32(p, stream, stllm_options().attn_f32_mfma);
   }
   stllm_set_error("stllm_attention: bad dtype %d", dtype);
   return STLLM_ERR_BAD_DTYPE;

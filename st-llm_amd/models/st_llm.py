@@ -109,10 +109,14 @@ class STLLMModel(Blip2Base):
         clip — rank r encodes AND prefills the clips c with c % world == r, no collective (SURVEY.md §8e "shard by clip")."""
         self.frame_parallel = (rank, world, group) if world > 1 else None
 
-    # encode time of one frame = 1; one prefilled clip of ~576 positions costs about this many frames (algorithmic FLOPs 7.7 T vs
-    # 0.534 T per frame = 14.4, times the measured efficiency ratio of the ViT and Llama GEMM shapes on one MI355X: c2 spends
-    # 11.8 ms in the LLM and 0.96 ms per frame); used to level the frame ranges when a batch has fewer clips than ranks
-    prefill_cost_frames = 12.0
+    # encode time of one frame = 1; one prefilled clip of ~576 positions costs about this many frames; used to level the frame ranges when a
+    # batch has fewer clips than ranks.  Measured on one MI355X (round 4, bench.py frame_parallel_projection, config 3 at N = 8): a rank
+    # with 38 frames and no prefill takes 28.6 ms = 0.75 ms per frame at that batch size, a rank with 26 frames + one prefill (S = 580)
+    # 32.4 ms; with 24 / 40 frames: 31.9 / 28.4 ms.  A rank's encode is NOT proportional to its frames — t(F) ~ 7 ms + 0.53 ms x F (launch-
+    # bound small kernels, per-GEMM prologues / epilogues, tile quantisation at M = 257 F rows) — so what levels the ranks is the prefill's
+    # 12 ms over the MARGINAL frame cost: 12 / 0.53 = 22 frames.  (Rounds 1-3 used 12, from c2's 11.8 ms of LLM time and 0.96 ms per frame
+    # at 16 frames: the 26 / 38 split it gave left the prefill ranks 3.8 ms behind; 22 gives 21 / 43.)
+    prefill_cost_frames = 22.0
 
     def _prefill_load(self, n_clips, T, world):
         """frames-equivalent of the prefill work of every rank (clip c -> rank c % world), scaled with the visual tokens per clip"""

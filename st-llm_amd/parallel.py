@@ -14,7 +14,7 @@ SURVEY.md §2b); correctness criterion: the gathered token block is bit-identica
      speed-up at the ViT/LLM FLOP ratio, SURVEY.md §7 hard-part 3);
   4. with fewer clips than GPUs (config 3: 4 clips on 8 GPUs) the frame ranges are NOT equal: a rank that also prefills a clip
      gets fewer frames than a rank that does not (frame_counts: one prefill ~ 12 frames of encode at S = 576), so that all
-     ranks finish together — 26 / 38 frames instead of 32 / 32 in config 3 at N = 8;
+     ranks finish together — 21 / 43 frames instead of 32 / 32 in config 3 at N = 8 (one prefill ~ 22 marginal frames: measured, round 4);
   5. when the frame ranges coincide with the clips every rank prefills (one clip per GPU: bench.py's weak-scaling config 2 at
      N > 1) the all-gather would move 8.4 MB per rank that nobody reads: gather_needed() is False and the collective is skipped.
 """

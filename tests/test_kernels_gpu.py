@@ -852,10 +852,12 @@ def test_attention(hip, dtype, case, dma):
     """every attention shape of the path against fp64; `attn_dma`: 1 = default (head_dim 128 on the LDS-DMA kernel with the hardware
     transposing V reads, head_dim 88 likewise), 0 = the register-staged kernels everywhere"""
     hip.set_option("attn_dma", dma)
+    hip.set_option("attn_f32_mfma", dma)   # fp32: 1 = the exact-fp32 matrix-core kernel (round 4: attn_mfma_f32_kernel), 0 = the one-wave-per-row vector kernel
     try:
         _attention_case(hip, dtype, case)
     finally:
         hip.set_option("attn_dma", 1)
+        hip.set_option("attn_f32_mfma", 1)
 
 
 def _attention_case(hip, dtype, case):
@@ -884,7 +886,7 @@ def _attention_case(hip, dtype, case):
     check(out, ref, 2 * OUT_TOL[dtype] if dtype != "fp32" else 2e-5, f"attention {case[0]}")
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
 def test_attention_online_softmax_rescale(hip, dtype):
     """Force the running max to jump late (rule 26): one key far down the sequence dominates."""
     B, H, S, D = 1, 2, 160, 128
@@ -896,7 +898,7 @@ def test_attention_online_softmax_rescale(hip, dtype):
     r = lambda t: t.view(1, S, H, D).transpose(1, 2)
     ref = _attn_ref(r(q64), r(k64), r(v64), D ** -0.5, False, None).transpose(1, 2).reshape(S, H * D)
     out = hip.attention(q, k, v, B=B, H=H, Sq=S, Skv=S, D=D, scale=D ** -0.5)
-    check(out, ref, 2 * OUT_TOL[dtype], "late-max rescale")
+    check(out, ref, 2 * OUT_TOL[dtype] if dtype != "fp32" else 2e-5, "late-max rescale")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -460,6 +460,64 @@ def test_c2_full_size_vs_reference():
     assert abs(res["bf16"][2] - g["loss"][0]) <= 0.05 and abs(res["fp16"][2] - g["loss"][0]) <= 0.01
 
 
+FULL_CASES = {   # BASELINE configs[2..4] at FULL SIZE: (model config, clips, frames, text Q-Former) — bench.CONFIGS' entries, as tests/golden/make_fixtures.py fx_full ran them
+    "c3": (dict(vit_model="eva_clip_g", video_input="residual", residual_size=16, use_mask=False, mvm_decode=False, qformer_text_input=True, max_txt_len=64), 4, 64, True),
+    "c4": (dict(vit_model="eva_clip_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False, max_txt_len=32), 1, 32, False),
+    "c5": (dict(vit_model="eva_btadapter_g", video_input="all", use_mask=True, mvm_decode=True, qformer_text_input=False, max_txt_len=32), 1, 16, False),
+}
+
+
+@pytest.mark.parametrize("tag", ["c3", "c4", "c5"])
+def test_full_size_configs_3_4_5_vs_reference(tag):
+    """BASELINE configs[2] (B = 4 x T = 64, text Q-Former, global-local residual R = 16), configs[3] (T = 32, dynamic mask + MVM: two prefills,
+    S = 528 + 1088) and configs[4] (BT-Adapter backbone, mask + MVM) at FULL SIZE — 39 + 12 + 32 layers, bench.py's own samples — against the
+    summary of the logits the REFERENCE's forward produced on CPU in fp32 on the same inputs, synthetic weights and (c4 / c5) the mask it
+    drew (tests/golden/c{3,4,5}_full.npz; make_fixtures.py fx_full).  Verify mode inside the north-star's 1e-2 (also loss and loss_mvm);
+    the timed dtype measured and bounded."""
+    import os
+    import bench
+    from stllm_amd import hip, runtime
+    path = os.path.join(os.path.dirname(__file__), "golden", f"{tag}_full.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{tag}_full.npz not generated (tests/golden/make_fixtures.py {tag}_full)")
+    g = np.load(path)
+    mcfg, B, Tn, text = FULL_CASES[tag]
+    assert all(mcfg[k] == v for k, v in bench.CONFIGS[tag]["model"].items()) and (bench.CONFIGS[tag]["clips"] or 1, bench.CONFIGS[tag]["frames"]) == (B, Tn)
+    cfg = dict(dict(image_size=224, num_query_token=32, end_sym=" 2"), **mcfg)
+    model = build_stllm(cfg, vit_depth=39, qf_layers=12, llm_layers=32)
+    samples = bench.make_samples(B, Tn, "cuda", text=text)
+    if cfg["use_mask"]:
+        mask = bench.draw_mask(Tn * 32, B)
+        assert np.array_equal(mask.numpy(), g["mask"]), "the package's generator on the seeded numpy stream == the mask the reference drew"
+        samples["mask"] = mask
+    sm = model.model.stllm_model
+    res = {}
+    for mode in ("fp32", "bf16"):
+        with runtime.use_dtype(mode):
+            for m in (sm.visual_encoder, sm.Qformer.bert, model.model):
+                m.repack()
+            model._lm_packed = {}
+            out = model(samples=samples)
+        assert out.logits.shape[0] == B and out.logits.shape[1] == int(g["seq_len"][0])
+        lg = out.logits.float().cpu()
+        err = float(np.abs(lg[:, ::3, ::499].numpy() - g["logits_slice"]).max())
+        agree = float((lg.argmax(-1).numpy() == g["top_ids"][..., 0]).mean())
+        res[mode] = (err, agree, float(out.loss.item()))
+        mvm = f", loss_mvm {float(out.loss_mvm):.5f} vs {g['loss_mvm'][0]:.5f}" if cfg["use_mask"] else ""
+        print(f"\n[{tag}_full {mode}] S={lg.shape[1]} logits max-abs err {err:.3e} (abs-max {g['logits_stats'][1]:.2f}), top-1 agreement {agree:.4f}, "
+              f"loss {out.loss.item():.5f} vs {g['loss'][0]:.5f}{mvm}")
+        if mode == "fp32":
+            top = lg.topk(5, dim=-1)
+            assert err <= 1e-2 and agree >= 0.99
+            assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
+            assert np.abs(lg.norm(dim=-1).numpy() - g["row_norms"]).max() <= 1e-2 * g["row_norms"].max()
+            assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
+            if cfg["use_mask"]:
+                assert (sm.img_len, sm.mask_img_len) == tuple(g["img_len"]) and abs(float(out.loss_mvm) - g["loss_mvm"][0]) <= 1e-4
+    assert res["bf16"][0] <= 0.30 and res["bf16"][1] >= 0.90 and abs(res["bf16"][2] - g["loss"][0]) <= 0.06, res["bf16"]
+    assert hip.gemm_workspace_ok()
+
+
 def test_c2_full_size_split_verify_mode():
     """Round 4: the SPLIT verify mode ("bf16x3": fp32 activations / norms / attention, every Linear as three bf16 matrix-core products of
     split operands, stllm_hip.h STLLM_BF16X3) on the benchmarked workload against the reference's own CPU fp32 logits — inside the
@@ -494,8 +552,9 @@ def test_c2_full_size_split_verify_mode():
     assert err <= 1e-2 and agree >= 0.99
     assert abs(out.loss.item() - g["loss"][0]) <= 1e-3
     assert model.model.layers[0].self_attn.q_proj.weight.dtype == torch.float32      # masters untouched; the packed copies are the split ones
-    pk = model.model.pack()
-    assert pk[0]["wo"].dtype == torch.float32, "leaving the mode re-packs plain fp32 weights"
+    with runtime.use_dtype("fp32"):
+        pk = model.model.pack()
+    assert pk[0]["wo"].dtype == torch.float32 and pk[0]["wo"].shape == (4096, 4096), "the plain verify mode re-packs plain fp32 weights"
 
 
 def test_generate_on_device_matches_reference_ids():

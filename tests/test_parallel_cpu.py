@@ -74,6 +74,7 @@ def test_frame_range_and_clip_ownership():
     assert owned == [0, 1, 2, 3]
     # config 3 on 8 GPUs: 4 clips x 64 frames, ranks 0-3 also prefill one clip (~12 frames of work each)
     assert parallel.frame_counts(256, 8, [12.0] * 4 + [0.0] * 4) == [26, 26, 26, 26, 38, 38, 38, 38]
+    assert parallel.frame_counts(256, 8, [22.0] * 4 + [0.0] * 4) == [21, 21, 21, 21, 43, 43, 43, 43]   # STLLMModel.prefill_cost_frames as measured in round 4
     assert parallel.frame_counts(256, 8, [12.0] * 8) == [32] * 8 == parallel.frame_counts(256, 8)
     for n in (1, 7, 16, 64, 256):
         for w in (2, 4, 8):
