@@ -124,10 +124,19 @@ class LlamaModel(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
     def rope(self, S, device):
-        if S not in self._rope:
+        """cos / sin tables [S, 64] on the device, cached per (S, device) — a handful of entries, oldest dropped.  The MVM forward alternates
+        two sequence lengths inside ONE step (masked and un-masked prefill, st_llm.py:56-92): with a single-entry cache (rounds 1-3) every
+        prefill rebuilt the tables on the host and copied them from pageable memory — a device synchronisation that cost configs c4 / c5
+        40-50 ms of idle GPU per step (profiles/r04_mvm_host_stall.md)."""
+        key = (S, str(device))
+        hit = self._rope.get(key)
+        if hit is None:
             d = self.config.hidden_size // self.config.num_attention_heads
-            self._rope = {S: pack.rope_tables(S, d, self.config.rope_theta, device)}
-        return self._rope[S]
+            hit = pack.rope_tables(S, d, self.config.rope_theta, device)
+            if len(self._rope) >= 8:
+                self._rope.pop(next(iter(self._rope)))
+            self._rope[key] = hit
+        return hit
 
     def prefill(self, inputs_embeds, attention_mask=None, cache=None):
         """inputs_embeds f32 [B,S,D]; attention_mask [B,S] (1 = token, right-padded) or None; cache: KVCache to fill.

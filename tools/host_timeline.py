@@ -2,7 +2,7 @@
 """Is the host ahead of the GPU?  Wraps the stllm_amd.hip entry points of one bench step and records, at every call, the host clock and
 whether the stream is already idle (stream.query() == True: everything enqueued so far has finished = the GPU is waiting for the host).
 
-    python tools/host_timeline.py [--steps 3]"""
+    python tools/host_timeline.py [--steps 3] [--config c2|c3|c4|c5]"""
 import argparse
 import os
 import sys
@@ -18,13 +18,18 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(bench.CONFIGS))
     a = ap.parse_args()
     torch.set_grad_enabled(False)
     from stllm_amd import hip, runtime
     runtime.set_compute_dtype("bf16")
     args = argparse.Namespace(vit_depth=39, qformer_layers=12, llm_layers=32)
-    model = bench.build_model(torch.device("cuda:0"), args)
-    samples = bench.make_samples(1, 16, "cuda:0")
+    conf = bench.CONFIGS[a.config]
+    model = bench.build_model(torch.device("cuda:0"), args, conf["model"])
+    B, T = conf["clips"] or 1, conf["frames"]
+    samples = bench.make_samples(B, T, "cuda:0", text=conf["model"]["qformer_text_input"])
+    if conf["model"].get("use_mask"):
+        samples["mask"] = bench.draw_mask((conf["model"].get("residual_size") if conf["model"]["video_input"] == "residual" else T) * 32, B)
     for _ in range(3):
         model(samples=samples)
     torch.cuda.synchronize()
