@@ -624,7 +624,7 @@ def _run(args, world, rank, device, dry):
         if rank == 0:
             cal = prof.summary()
             # the timed region: HIP events around every 7th launch of the dominant symbol (an odd period: its two alternating shapes are both
-            # sampled); events around ALL of its 78 launches per step slowed the step they measure by 2 % (DESIGN §6.0)
+            # sampled); events around ALL of its 78 launches per step slowed the step they measure by 2 % (DESIGN §6.1)
             prof.start_target(max(cal, key=lambda k: cal[k]["total_ms"]), sampled=True)
     # ---- timed region: EXACTLY K steps between barrier + synchronize ---------------------------------
     # The K steps run as up to 3 blocks with a device synchronisation (no barrier) between them: the blocks' own times show the spread
