@@ -28,11 +28,19 @@ constexpr bool kUsePrefetchWave = false;  // experimental 5th wave that pulls fu
 constexpr int kThreads = kUsePrefetchWave ? 320 : 256;   // 4 MFMA waves (+ 1 L2-prefetch wave)
 constexpr int kPrefetchDist = 6; // panels the prefetch wave runs ahead of the MFMA waves
 
+#ifndef STLLM_GEMM_RING64
+#define STLLM_GEMM_RING64 4   // LDS ring depth of the 64 x 64 tile (2 = rounds 1-3; A/B builds: -DSTLLM_GEMM_RING64=2)
+#endif
 template <int BM, int BN> struct Tile {
   static constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   static constexpr int kStageBytes = (BM + BN) * kRowBytes;
-  static constexpr int kPfScratch = 256;                    // landing pad of the L2-prefetch wave's LDS-DMA
-  static constexpr int kLdsBytes = 2 * kStageBytes + kPfScratch;
+  // Ring depth.  The 64 x 64 tile serves the small problems (Q-Former: M = 512 rows, K = 768 / 3072): a K panel of it is ~200 cycles of
+  // matrix work per wave against a ~1000-cycle L2 round trip, so with two stages ("wait for everything, barrier, request the next panel")
+  // the loop ran at one L2 latency per panel: 0.55 us x 12 .. 48 panels.  Four stages (16 KiB each) keep three panels in flight behind a
+  // counted wait (round 4).  The 128-row tiles stay at two (32-48 KiB per stage, two workgroups per CU).
+  static constexpr int kStages = (BM == 64 && BN == 64) ? STLLM_GEMM_RING64 : 2;
+  static constexpr int kPfScratch = 1024;                   // landing pad: the L2-prefetch wave's LDS-DMA / the pieces issued past the end of the panel stream
+  static constexpr int kLdsBytes = kStages * kStageBytes + kPfScratch;
   // resident workgroups per CU: LDS-limited (160 KiB), at most 6 (5 waves each, 32 waves per CU)
   static constexpr int kWavesPerWG = kThreads / 64;
   static constexpr int kPerCU = (160 * 1024 / kLdsBytes) < (32 / kWavesPerWG) ? (160 * 1024 / kLdsBytes) : (32 / kWavesPerWG);
@@ -154,12 +162,34 @@ __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kerne
   if (w >= ntiles) return;
   int tm, tn;
   tile_coords(w, p.tiles_m, p.tiles_n, tm, tn);
+  constexpr int NS = TL::kStages;
+  int it = 0;  // running panel counter: panel `it` lives in LDS stage it % NS
+  char* pf_pad = smem + NS * TL::kStageBytes;
+  // ---- the panel stream of this workgroup, flattened over its tiles: an ISSUE cursor (tile iw, panel it_iss) runs NS - 1 panels ahead of
+  // the compute loop.  Every call requests exactly kPiecesPerWave pieces per wave — past the end of the stream into the landing pad — so
+  // that the loop's counted wait (vmcnt retires in order) always means "panel `it` has landed".
+  int iw = w, it_iss = 0, im = tm, in_ = tn;
+  auto issue_next = [&](int buf) {
+    if (iw < ntiles) {
+      stage(im * BM, it_iss, buf);
+      if (++it_iss == nk) {
+        iw += G;
+        it_iss = 0;
+        if (iw < ntiles) {
+          tile_coords(iw, p.tiles_m, p.tiles_n, im, in_);
+          plan(im * BM, in_ * BN);
+        }
+      }
+    } else if (!(p.debug & 1)) {
+#pragma unroll
+      for (int j = 0; j < kPiecesPerWave; ++j) glds16(p.W + (lane & 7) * 16, pf_pad);
+    }
+  };
   if (!is_pf) {
     plan(tm * BM, tn * BN);
-    stage(tm * BM, 0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_) issue_next(s_);
   }
-  int it = 0;  // running panel counter: panel `it` lives in LDS stage it & 1
-  char* pf_pad = smem + 2 * TL::kStageBytes;
   const int pos = blockIdx.x >> 3;  // position of this workgroup inside its XCD's contiguous run of tiles
 
   // L2 prefetch of one K panel of a tile: one 4-byte LDS-DMA per 128-byte line (the data is discarded; the
@@ -226,17 +256,13 @@ __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kerne
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     for (int t = 0; t < nk; ++t, ++it) {
-      const int cur = it & 1;
-      // panel `it` has landed (each wave waits for its own pieces, the barrier publishes all of them)
-      // and every wave is done reading stage cur^1 (panel it-1 / the previous tile's epilogue)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int cur = it % NS;
+      // panel `it` has landed (each wave waits for its own pieces — the NS - 2 younger panels may stay in flight —, the barrier publishes
+      // all of them) and every wave is done reading the stage of panel it - 1 (or the previous tile's epilogue scratch), which the
+      // request below overwrites.  The stream is flattened over the tiles: the next tile's first panels fly under this tile's epilogue.
+      wait_vmcnt<(NS - 2) * kPiecesPerWave>();
       STLLM_BAR();
-      if (t + 1 < nk) {
-        stage(m0, t + 1, cur ^ 1);
-      } else if (w_next < ntiles) {  // flattened stream: next tile's first panel flies under this tile's epilogue
-        plan(tm_n * BM, tn_n * BN);
-        stage(tm_n * BM, 0, cur ^ 1);
-      }
+      issue_next((it + NS - 1) % NS);
       const char* base = smem + cur * TL::kStageBytes;
       if (p.debug & 2) continue;
 #pragma unroll
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(kThreads, kUsePrefetchWave ? 3 : 2) void gemm_kerne
     // ---- epilogue: raw fp32 accumulators -> LDS stage just consumed -> (bias / act / RoPE / SwiGLU / residual)
     //      applied by the copy-out threads on whole rows -> coalesced 16-byte global stores.
     // C layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    char* ep = smem + ((it - 1) & 1) * TL::kStageBytes;  // the other stage is receiving the next tile's panel
+    char* ep = smem + ((it - 1) % NS) * TL::kStageBytes;  // the stage consumed last; the others are receiving the next panels
     constexpr bool kOutT = (EPI == STLLM_EPI_SWIGLU || EPI == STLLM_EPI_ROPE);   // always compute-dtype out
     constexpr bool kOutF = (EPI == STLLM_EPI_RESID || EPI == STLLM_EPI_PATCH);   // always fp32 out
     constexpr bool f32out = kOutF || (!kOutT && (OF32 || Elem<T>::kIsF32));
