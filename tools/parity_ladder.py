@@ -5,7 +5,8 @@ Runs BASELINE config 2 at full size (bench.make_samples(1, 16)) with the compute
 (+ ln_vision + projector), Llama (+ lm_head) — and prints the logits error against the reference's own CPU fp32 forward
 (tests/golden/c2_full.npz).  GPU only.
 
-    python tools/parity_ladder.py [--modes fp16,bf16]
+    python tools/parity_ladder.py [--modes fp16,bf16] [--extra bf16x3/bf16x3/bf16x3,bf16x3/fp32/fp32]
+(stage modes: fp32 | fp16 | bf16 | bf16x3 = the split verify mode of round 4; every row also prints the step time of that combination)
 """
 import argparse
 import contextlib
@@ -48,12 +49,19 @@ def main():
         for m in (sm.visual_encoder, sm.Qformer.bert, model.model):
             m.repack()
         model._lm_packed = {}
+        import time
         with runtime.use_dtype(l):
-            out = model(samples=samples)
+            out = model(samples=samples)          # packs the weights of the three stages
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                out = model(samples=samples)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 3 * 1e3
         lg = out.logits[0].float().cpu()
         err = float(np.abs(lg[::3, ::499].numpy() - g["logits_slice"]).max())
         agree = float((lg.argmax(-1).numpy() == g["top_ids"][:, 0]).mean())
-        print(f"ViT {v:5s} Q-Former {q:5s} Llama {l:5s}: logits max-abs err {err:.3e}  top-1 {agree:.4f}  loss err {abs(out.loss.item() - float(g['loss'][0])):.2e}", flush=True)
+        print(f"ViT {v:6s} Q-Former {q:6s} Llama {l:6s}: logits max-abs err {err:.3e}  top-1 {agree:.4f}  loss err {abs(out.loss.item() - float(g['loss'][0])):.2e}  {ms:7.2f} ms/step", flush=True)
 
     run("fp32", "fp32", "fp32")
     for m in a.modes.split(","):
