@@ -120,8 +120,15 @@ typedef struct {
    * to the launch stream, no initialisation (the split A operand and, for SWIGLU, the fp32 gate/up columns).  (ABI 4's fold_* fields —
    * LayerNorm folded into the GEMMs, measured slower than the LayerNorm kernels — were removed with their kernels in ABI 5.) */
   void* split_ws; int64_t split_ws_bytes;
+  /* dtype STLLM_BF16X3 only — chaining two split GEMMs without an fp32 round trip between them:
+   *   STLLM_SPLIT_A_PRESPLIT: A is ALREADY the split image, bf16 [M, lda >= 3 K] = (hi | hi | lo) — written by stllm_layernorm / stllm_rmsnorm called with
+   *     dtype STLLM_BF16X3, by stllm_split3_rows, or by a previous GEMM with STLLM_SPLIT_OUT;
+   *   STLLM_SPLIT_OUT (STORE and SWIGLU epilogues): `out` receives the split image of the result, bf16 [M, ldo >= 3 N'] (N' = N, or N / 2 for SWIGLU), after the
+   *     activation — the A operand of the next GEMM — instead of the fp32 tensor.  The values are bit-identical to splitting the fp32 result afterwards. */
+  int split_flags;
 } stllm_gemm_args;
-int64_t stllm_gemm_split_ws_bytes(int M, int N, int K, int epilogue);
+enum { STLLM_SPLIT_A_PRESPLIT = 1, STLLM_SPLIT_OUT = 2 };
+int64_t stllm_gemm_split_ws_bytes(int M, int N, int K, int epilogue, int split_flags);
 /* x f32 [M, K] (row stride ldx; rows_per_batch / batch_stride: the 2-level row indexing of stllm_gemm_args, 0 = flat) ->
  * out bf16 [M, ldo >= 3 K]: hi = bf16(x), lo = bf16(x - hi), laid out (hi | hi | lo) along K for weight_side == 0 (the A operand) and
  * (hi | lo | hi) for weight_side != 0 (the weight: packed once).  K % 4 == 0. */
@@ -250,6 +257,8 @@ int stllm_preprocess_frames(const uint8_t* frames, int64_t frame_stride_bytes, i
 /*
  * LayerNorm over the last dim of x f32[M,D] (ldx), fp32 statistics (two-pass), affine.
  * Writes out_t T[M,D] (ldo_t) and/or out_f32 [M,D] (ldo_f); either may be NULL.
+ * dtype STLLM_BF16X3 (ABI >= 5): out_t is the split image bf16 [M, ldo_t >= 3 D] = (hi | hi | lo) of the fp32 result — the A operand of a bf16x3 GEMM
+ * called with STLLM_SPLIT_A_PRESPLIT (same for stllm_rmsnorm).
  * Replaces nn.LayerNorm at eva_vit.py:157,163 (eps 1e-6), blip2.py:103-109 (ln_vision, eps 1e-5),
  * Qformer.py:65,106,282,288,368,374 (eps 1e-12), st_llm.py:39 (mvm_decoder.norm).
  * D % 4 == 0, D <= 8192.

@@ -3,9 +3,43 @@
 // via wave shuffles; writes the compute-dtype copy (next GEMM's A operand) and/or an fp32 copy.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kMaxVec = 32;  // D <= 64 lanes * 4 floats * 32 = 8192
+
+// dtype STLLM_BF16X3 (the split verify mode): out_t is the A operand of the bf16x3 GEMM that follows — bf16 [M, ldo_t >= 3 D] = (hi | hi | lo) of the
+// fp32 result, hi = bf16(v), lo = bf16(v - hi): exactly what stllm_split3_rows would make of the fp32 copy, without writing and re-reading it.
+struct split3_t {};
+
+// four consecutive columns 4 c .. 4 c + 3 of row `row` in the compute dtype
+template <typename T>
+__device__ __forceinline__ void store_row4(void* out_t, int64_t row, int64_t ldo_t, int c, int D, float4 o) {
+  if constexpr (std::is_same<T, split3_t>::value) {
+    uint16_t h[4], l[4];
+    const float v[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = f32_to_bf16_bits(v[e]);
+      l[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(h[e]));
+    }
+    uint2 hv, lv;
+    hv.x = h[0] | ((uint32_t)h[1] << 16); hv.y = h[2] | ((uint32_t)h[3] << 16);
+    lv.x = l[0] | ((uint32_t)l[1] << 16); lv.y = l[2] | ((uint32_t)l[3] << 16);
+    uint16_t* op = reinterpret_cast<uint16_t*>(out_t) + row * ldo_t + 4 * c;
+    *reinterpret_cast<uint2*>(op) = hv;
+    *reinterpret_cast<uint2*>(op + D) = hv;
+    *reinterpret_cast<uint2*>(op + 2 * D) = lv;
+  } else if constexpr (Elem<T>::kIsF32) {
+    reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + row * ldo_t)[c] = o;
+  } else {
+    uint2 pk;
+    pk.x = Elem<T>::pack2(o.x, o.y);
+    pk.y = Elem<T>::pack2(o.z, o.w);
+    reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + row * ldo_t)[c] = pk;
+  }
+}
 
 template <typename T, bool RMS, int NV, int RW = 1>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int64_t ldx,
@@ -100,16 +134,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
         o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
       }
       if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
-      if (out_t) {
-        if constexpr (Elem<T>::kIsF32) {
-          reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
-        } else {
-          uint2 pk;
-          pk.x = Elem<T>::pack2(o.x, o.y);
-          pk.y = Elem<T>::pack2(o.z, o.w);
-          reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
-        }
-      }
+      if (out_t) store_row4<T>(out_t, row, ldo_t, c, D, o);
     }
   }
 }
@@ -185,16 +210,7 @@ __global__ __launch_bounds__(256) void norm_row_kernel(const float* __restrict__
       o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
     }
     if (out_f) reinterpret_cast<float4*>(out_f + (int64_t)row * ldo_f)[c] = o;
-    if (out_t) {
-      if constexpr (Elem<T>::kIsF32) {
-        reinterpret_cast<float4*>(reinterpret_cast<float*>(out_t) + (int64_t)row * ldo_t)[c] = o;
-      } else {
-        uint2 pk;
-        pk.x = Elem<T>::pack2(o.x, o.y);
-        pk.y = Elem<T>::pack2(o.z, o.w);
-        reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_t) + (int64_t)row * ldo_t)[c] = pk;
-      }
-    }
+    if (out_t) store_row4<T>(out_t, row, ldo_t, c, D, o);
   }
 }
 
@@ -250,6 +266,9 @@ int norm_entry(int dtype, const float* x, int64_t ldx, const float* gamma, const
     case STLLM_BF16: return launch_nv<bf16_t, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
     case STLLM_F16: return launch_nv<f16_t, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
     case STLLM_F32: return launch_nv<float, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
+    case STLLM_BF16X3:
+      if (out_t) STLLM_CHECK_ARG(ldo_t >= 3 * (int64_t)D, "%s(BF16X3): out_t is the split image bf16 [M, ldo_t >= 3 D]", nm);
+      return launch_nv<split3_t, RMS>(x, ldx, gamma, beta, eps, out_t, ldo_t, out_f, ldo_f, M, D, stream);
   }
   stllm_set_error("%s: bad dtype %d", nm, dtype);
   return STLLM_ERR_BAD_DTYPE;

@@ -40,11 +40,18 @@ stllm_gemm_args gemm_base(int dtype, void* ws, int64_t ws_bytes, void* split_ws,
   return g;
 }
 
-// split workspace that serves every GEMM of a decoder layer: the widest split A operand (down_proj: K = inter) next to the fp32 gate/up columns
-inline int64_t llama_split_ws(int M, int hidden, int inter) {
-  const int64_t a = stllm_gemm_split_ws_bytes(M, hidden, inter, STLLM_EPI_RESID), b = stllm_gemm_split_ws_bytes(M, 2 * inter, hidden, STLLM_EPI_SWIGLU);
+// Split verify mode (STLLM_BF16X3): the norms write the split image of their output straight away (h: bf16 [M, 3 D]), fc1 / gate-up write the
+// split image of their activation (STLLM_SPLIT_OUT), so only the attention outputs (fp32 from the attention kernel) are split inside their GEMM.
+// split workspace of a stack = the larger of: the split A operand of proj / o_proj, the fp32 temporary of fc1 / gate-up.
+inline int64_t vit_split_ws(int M, int dim, int hidden) {
+  const int64_t a = stllm_gemm_split_ws_bytes(M, dim, dim, STLLM_EPI_RESID, 0), b = stllm_gemm_split_ws_bytes(M, hidden, dim, STLLM_EPI_STORE, STLLM_SPLIT_A_PRESPLIT | STLLM_SPLIT_OUT);
   return a > b ? a : b;
 }
+inline int64_t llama_split_ws(int M, int hidden, int inter) {
+  const int64_t a = stllm_gemm_split_ws_bytes(M, hidden, hidden, STLLM_EPI_RESID, 0), b = stllm_gemm_split_ws_bytes(M, 2 * inter, hidden, STLLM_EPI_SWIGLU, STLLM_SPLIT_A_PRESPLIT | STLLM_SPLIT_OUT);
+  return a > b ? a : b;
+}
+inline int64_t hsize(int dtype) { return dtype == STLLM_BF16X3 ? 6 : esize(dtype); }   // bytes per element of a GEMM's A operand written by a norm / an activation
 
 }  // namespace
 
@@ -56,9 +63,9 @@ inline int64_t llama_split_ws(int M, int hidden, int inter) {
 
 extern "C" int64_t stllm_vit_blocks_scratch_bytes(int dtype, int n_seq, int seq_len, int dim, int hidden) {
   if (n_seq <= 0 || seq_len <= 0 || dim <= 0 || hidden <= 0 || !dtype_ok(dtype)) return -1;
-  const int64_t M = (int64_t)n_seq * seq_len, e = esize(dtype);
-  int64_t need = up256(M * dim * e) * 2 + up256(M * 3 * dim * e) + up256(M * hidden * e);
-  if (dtype == STLLM_BF16X3) need += up256(stllm_gemm_split_ws_bytes((int)M, dim, hidden > dim ? hidden : dim, STLLM_EPI_STORE));   // the split A operand of the widest GEMM
+  const int64_t M = (int64_t)n_seq * seq_len, e = esize(dtype), eh = hsize(dtype);
+  int64_t need = up256(M * dim * eh) + up256(M * dim * e) + up256(M * 3 * dim * e) + up256(M * hidden * eh);
+  if (dtype == STLLM_BF16X3) need += up256(vit_split_ws((int)M, dim, hidden));
   return need;
 }
 
@@ -77,17 +84,19 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
     stllm_set_error("stllm_vit_blocks: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
     return STLLM_ERR_BAD_SHAPE;
   }
-  const int M = a->n_seq * a->seq_len, D = a->dim, hd = D / a->num_heads, e = esize(a->dtype);
-  const int adt = act_dtype(a->dtype);   // norms / attention: the activations' dtype (fp32 in the split mode)
+  const int M = a->n_seq * a->seq_len, D = a->dim, hd = D / a->num_heads, e = esize(a->dtype), eh = (int)hsize(a->dtype);
+  const bool x3 = a->dtype == STLLM_BF16X3;
+  const int adt = act_dtype(a->dtype);   // attention: the activations' dtype (fp32 in the split mode)
+  const int64_t ldh = x3 ? 3 * (int64_t)D : D, ldg = x3 ? 3 * (int64_t)a->hidden : a->hidden;   // row strides of the norm / GELU outputs (split images in the split mode)
   Carver c(a->scratch, a->scratch_bytes);
-  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * eh));
   char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* qkv = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
-  char* g1 = reinterpret_cast<char*>(c.take((int64_t)M * a->hidden * e));
+  char* g1 = reinterpret_cast<char*>(c.take((int64_t)M * a->hidden * eh));
   void* sws = nullptr;
   int64_t sws_bytes = 0;
-  if (a->dtype == STLLM_BF16X3) {
-    sws_bytes = stllm_gemm_split_ws_bytes(M, D, a->hidden > D ? a->hidden : D, STLLM_EPI_STORE);
+  if (x3) {
+    sws_bytes = vit_split_ws(M, D, a->hidden);
     sws = c.take(sws_bytes);
   }
   float scale = 1.0f;
@@ -99,8 +108,9 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
   for (int b = 0; b < n_blocks; ++b) {
     const stllm_vit_block_weights& w = blocks[b];
     stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    STACK_TRY(stllm_layernorm(adt, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, D, nullptr, 0, M, D, stream));
-    g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
+    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n1w, w.n1b, w.e1, h, ldh, nullptr, 0, M, D, stream));
+    g.epilogue = STLLM_EPI_STORE; g.A = h; g.lda = ldh; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT;
     g.out = qkv; g.ldo = 3 * D; g.M = M; g.N = 3 * D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     const int64_t rs = 3 * D, bs = (int64_t)a->seq_len * rs;
@@ -111,12 +121,14 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    STACK_TRY(stllm_layernorm(adt, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, D, nullptr, 0, M, D, stream));
-    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = D; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
-    g.out = g1; g.ldo = a->hidden; g.M = M; g.N = a->hidden; g.K = D;
+    STACK_TRY(stllm_layernorm(a->dtype, a->x, a->ldx, w.n2w, w.n2b, w.e2, h, ldh, nullptr, 0, M, D, stream));
+    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = h; g.lda = ldh; g.W = w.wfc1; g.ldw = w.ld_fc1; g.bias = w.bfc1;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT | STLLM_SPLIT_OUT;   // GELU(fc1) leaves as the split A operand of fc2
+    g.out = g1; g.ldo = ldg; g.M = M; g.N = a->hidden; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    g.epilogue = STLLM_EPI_RESID; g.A = g1; g.lda = a->hidden; g.W = w.wfc2; g.ldw = w.ld_fc2; g.bias = w.bfc2;
+    g.epilogue = STLLM_EPI_RESID; g.A = g1; g.lda = ldg; g.W = w.wfc2; g.ldw = w.ld_fc2; g.bias = w.bfc2;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->hidden;
     STACK_TRY(stllm_gemm(&g, stream));
   }
@@ -125,8 +137,8 @@ extern "C" int stllm_vit_blocks(const stllm_vit_blocks_args* a, const stllm_vit_
 
 extern "C" int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, int inter) {
   if (B <= 0 || S <= 0 || hidden <= 0 || inter <= 0 || !dtype_ok(dtype)) return -1;
-  const int64_t M = (int64_t)B * S, e = esize(dtype);
-  int64_t need = up256(M * hidden * e) * 2 + up256(M * 3 * hidden * e) + up256(M * inter * e);
+  const int64_t M = (int64_t)B * S, e = esize(dtype), eh = hsize(dtype);
+  int64_t need = up256(M * hidden * eh) + up256(M * hidden * e) + up256(M * 3 * hidden * e) + up256(M * inter * eh);
   if (dtype == STLLM_BF16X3) need += up256(llama_split_ws((int)M, hidden, inter));
   return need;
 }
@@ -148,16 +160,18 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
     stllm_set_error("stllm_llama_layers: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
     return STLLM_ERR_BAD_SHAPE;
   }
-  const int M = a->B * a->S, D = a->hidden, hd = D / a->n_heads, e = esize(a->dtype);
+  const int M = a->B * a->S, D = a->hidden, hd = D / a->n_heads, e = esize(a->dtype), eh = (int)hsize(a->dtype);
+  const bool x3 = a->dtype == STLLM_BF16X3;
+  const int64_t ldh = x3 ? 3 * (int64_t)D : D, ldg = x3 ? 3 * (int64_t)a->inter : a->inter;
   if (a->cache_max_len != 0 && (a->cache_max_len < a->S || a->kv_len != nullptr)) {
     stllm_set_error("stllm_llama_layers: the KV cache needs max_len >= S and equal-length sequences");
     return STLLM_ERR_BAD_SHAPE;
   }
   Carver c(a->scratch, a->scratch_bytes);
-  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
+  char* h = reinterpret_cast<char*>(c.take((int64_t)M * D * eh));
   char* att = reinterpret_cast<char*>(c.take((int64_t)M * D * e));
   char* qkv_s = reinterpret_cast<char*>(c.take((int64_t)M * 3 * D * e));
-  char* gu = reinterpret_cast<char*>(c.take((int64_t)M * a->inter * e));
+  char* gu = reinterpret_cast<char*>(c.take((int64_t)M * a->inter * eh));
   void* sws = nullptr;
   int64_t sws_bytes = 0;
   if (a->dtype == STLLM_BF16X3) {
@@ -168,9 +182,10 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
   const float scale = (float)(1.0 / __builtin_sqrt((double)hd));
   for (int l = 0; l < n_layers; ++l) {
     const stllm_llama_layer_weights& w = layers[l];
-    STACK_TRY(stllm_rmsnorm(adt, a->x, a->ldx, w.ln1, a->eps, h, D, nullptr, 0, M, D, stream));
+    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln1, a->eps, h, ldh, nullptr, 0, M, D, stream));
     stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv;
+    g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = ldh; g.W = w.wqkv; g.ldw = w.ld_qkv;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT;
     g.aux0 = a->rope_cos; g.aux1 = a->rope_sin; g.rope_seq = a->S; g.rope_cols = 2 * D; g.M = M; g.N = 3 * D; g.K = D; g.ldo = 3 * D;
     char* qkv = qkv_s;
     int64_t bs = (int64_t)a->S * 3 * D;
@@ -189,13 +204,15 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
     g.epilogue = STLLM_EPI_RESID; g.A = att; g.lda = D; g.W = w.wo; g.ldw = w.ld_o;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
-    STACK_TRY(stllm_rmsnorm(adt, a->x, a->ldx, w.ln2, a->eps, h, D, nullptr, 0, M, D, stream));
+    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln2, a->eps, h, ldh, nullptr, 0, M, D, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = D; g.W = w.wgu; g.ldw = w.ld_gu;
-    g.out = gu; g.ldo = a->inter; g.M = M; g.N = 2 * a->inter; g.K = D;
+    g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = ldh; g.W = w.wgu; g.ldw = w.ld_gu;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT | STLLM_SPLIT_OUT;   // SiLU(gate) * up leaves as the split A operand of down_proj
+    g.out = gu; g.ldo = ldg; g.M = M; g.N = 2 * a->inter; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
-    g.epilogue = STLLM_EPI_RESID; g.A = gu; g.lda = a->inter; g.W = w.wdown; g.ldw = w.ld_down;
+    g.epilogue = STLLM_EPI_RESID; g.A = gu; g.lda = ldg; g.W = w.wdown; g.ldw = w.ld_down;
+    if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT;
     g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = M; g.N = D; g.K = a->inter;
     STACK_TRY(stllm_gemm(&g, stream));
   }

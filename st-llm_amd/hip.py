@@ -47,7 +47,7 @@ class GemmArgs(ctypes.Structure):
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float),
-                ("split_ws", c_void_p), ("split_ws_bytes", c_int64)]
+                ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("split_flags", c_int)]
 
 
 class VitBlockWeights(ctypes.Structure):
@@ -122,7 +122,7 @@ def _bind(L, strict=True):
     B("stllm_gemm_profile_count", [])
     B("stllm_gemm_profile_read", [c_int, c_char_p, c_int, ctypes.POINTER(c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)])
     B("stllm_split3_rows", [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p])
-    B("stllm_gemm_split_ws_bytes", [c_int] * 4, c_int64)
+    B("stllm_gemm_split_ws_bytes", [c_int] * 5, c_int64)
     B("stllm_vit_blocks_scratch_bytes", [c_int] * 5, c_int64)
     B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
     B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
@@ -398,10 +398,12 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None, a_norm=None):
+         a_rows=None, o_rows=None, a_norm=None, a_presplit=False, out_split=False):
     """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
     dtype fp32 with a bf16 weight of 3 K columns (pack.split3_weight: the runtime's "bf16x3" mode) selects STLLM_BF16X3: a and every output
-    stay fp32, the product runs as three bf16 matrix-core passes (stllm_hip.h).
+    stay fp32, the product runs as three bf16 matrix-core passes (stllm_hip.h).  In that mode a_presplit = a is ALREADY the split image bf16 [M, 3 K]
+    (layernorm / rmsnorm with dtype "bf16x3", split3, or a previous gemm with out_split), out_split (STORE / SWIGLU) = return the split image of the
+    result, bf16 [M, 3 N'], instead of the fp32 tensor — what stllm_vit_blocks / stllm_llama_layers chain internally.
     a_norm=(x, gamma, eps) with a=None (decode regime, M <= 8, 16-bit dtypes): the A operand is RMSNorm(x) * gamma of the fp32
     rows x [M,K], computed inside the kernel (stllm_hip.h: a_norm_*)."""
     td = torch_dtype(dtype)
@@ -427,8 +429,14 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         args.A, args.lda = None, 0
         args.a_norm_x, args.a_norm_ldx, args.a_norm_gamma, args.a_norm_eps = _p(xn), xn.stride(-2), _p(gamma), float(eps)
     else:
-        _req(a, td, "A")
-        K = a.shape[-1]
+        if a_presplit:
+            if not split:
+                raise RuntimeError("gemm: a_presplit needs the bf16x3 mode (fp32 dtype, split bf16 weight)")
+            _req(a, torch.bfloat16, "A (pre-split)")
+            K = a.shape[-1] // 3
+        else:
+            _req(a, td, "A")
+            K = a.shape[-1]
         if a_rows is not None:  # (rows_per_batch, batch_stride): 2-level rows inside a larger buffer
             args.a_rows_per_batch, args.a_batch_stride = a_rows
             if M is None:
@@ -449,9 +457,16 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         _req(out, torch.float32, "out")
     else:
         n_out = N // 2 if epilogue == EPI_SWIGLU else N
-        if out is None:
-            out = torch.empty((M, n_out), device=w.device, dtype=torch.float32 if out_f32 else td)
-        _req(out, torch.float32 if out_f32 else td, "out")
+        if out_split:
+            if not split or epilogue not in (EPI_STORE, EPI_SWIGLU):
+                raise RuntimeError("gemm: out_split needs the bf16x3 mode and a STORE / SWIGLU epilogue")
+            if out is None:
+                out = torch.empty((M, 3 * n_out), device=w.device, dtype=torch.bfloat16)
+            _req(out, torch.bfloat16, "out (split)")
+        else:
+            if out is None:
+                out = torch.empty((M, n_out), device=w.device, dtype=torch.float32 if out_f32 else td)
+            _req(out, torch.float32 if out_f32 else td, "out")
     if epilogue == EPI_ROPE:
         cos, sin = rope
         _req(cos, torch.float32, "rope cos"); _req(sin, torch.float32, "rope sin")
@@ -463,7 +478,8 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
     if split:
         if w.shape[1] != 3 * K:
             raise RuntimeError(f"gemm(bf16x3): the split weight must have 3 K = {3 * K} columns, got {w.shape[1]}")
-        need = int(lib().stllm_gemm_split_ws_bytes(M, N, K, epilogue))
+        args.split_flags = (1 if a_presplit else 0) | (2 if out_split else 0)
+        need = int(lib().stllm_gemm_split_ws_bytes(M, N, K, epilogue, args.split_flags))
         sws = split_workspace(w.device, need)
         args.split_ws, args.split_ws_bytes = _p(sws), sws.numel()
     ws = gemm_workspace(w.device)
@@ -566,16 +582,24 @@ def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=Non
     return x
 
 
+def _norm_dtype(dtype, D):
+    """(C dtype code, torch dtype of out_t, columns of out_t): dtype "bf16x3" = the split image bf16 [M, 3 D] (stllm_hip.h)"""
+    if isinstance(dtype, str) and dtype in ("bf16x3", "split"):
+        return BF16X3, torch.bfloat16, 3 * D
+    td = torch_dtype(dtype)
+    return dtype_code(td), td, D
+
+
 def layernorm(x, gamma, beta, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
     """x f32 [M,D] -> (out_t compute-dtype [M,D] | None, out_f32 | None)."""
     _req(x, torch.float32, "x")
     M, D = x.shape
-    td = torch_dtype(dtype)
+    code, td, wt = _norm_dtype(dtype, D)
     if want_t and out_t is None:
-        out_t = torch.empty((M, D), device=x.device, dtype=td)
+        out_t = torch.empty((M, wt), device=x.device, dtype=td)
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty((M, D), device=x.device, dtype=torch.float32)
-    _check(lib().stllm_layernorm(dtype_code(td), _p(x), x.stride(0), _p(gamma), _p(beta), eps,
+    _check(lib().stllm_layernorm(code, _p(x), x.stride(0), _p(gamma), _p(beta), eps,
                                  _p(out_t), out_t.stride(0) if out_t is not None else 0,
                                  _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0, M, D, _stream()),
            "stllm_layernorm")
@@ -585,12 +609,12 @@ def layernorm(x, gamma, beta, eps, *, dtype, out_t=None, out_f32=None, want_t=Tr
 def rmsnorm(x, gamma, eps, *, dtype, out_t=None, out_f32=None, want_t=True, want_f32=False):
     _req(x, torch.float32, "x")
     M, D = x.shape
-    td = torch_dtype(dtype)
+    code, td, wt = _norm_dtype(dtype, D)
     if want_t and out_t is None:
-        out_t = torch.empty((M, D), device=x.device, dtype=td)
+        out_t = torch.empty((M, wt), device=x.device, dtype=td)
     if want_f32 and out_f32 is None:
         out_f32 = torch.empty((M, D), device=x.device, dtype=torch.float32)
-    _check(lib().stllm_rmsnorm(dtype_code(td), _p(x), x.stride(0), _p(gamma), eps,
+    _check(lib().stllm_rmsnorm(code, _p(x), x.stride(0), _p(gamma), eps,
                                _p(out_t), out_t.stride(0) if out_t is not None else 0,
                                _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0, M, D, _stream()),
            "stllm_rmsnorm")

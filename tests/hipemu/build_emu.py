@@ -16,7 +16,8 @@ DYN = "#include <hip/hip_runtime.h>\nnamespace {{ alignas(16) {type} smem[{n}]; 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     lib = os.path.join(OUT, "libstllm_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp", "stacks.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "p8_stubs.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in KERNEL_SOURCES + ["common.h", "gemm_common.h", "error.cpp", "stacks.cpp"]] + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "p8_stubs.cpp"),
+                                                                                                          os.path.join(ROOT, "include", "stllm_hip.h"), os.path.join(CSRC, "options.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in srcs):
         return lib
     tus = []

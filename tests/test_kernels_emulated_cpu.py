@@ -519,6 +519,28 @@ def test_emulated_bf16x3_gemm_every_epilogue():
     for n in want:
         assert got[n].dtype == torch.float32
         close(got[n], want[n], 2e-5, f"bf16x3 gemm {n}")
+    # chaining without the fp32 round trips (what stllm_vit_blocks / stllm_llama_layers do in this mode): the norms write the split image,
+    # the GEMM takes it as is (a_presplit) and hands the split image of GELU / SwiGLU to the next GEMM (out_split) — bit-identical to the unfused calls
+    gam, bet = rnd(K, seed=195) + 1.0, rnd(K, seed=196)
+    w2 = rnd(K, N, seed=197, scale=0.1)                      # second GEMM: [N -> K]
+    w2s, wg3 = pack.split3_weight(w2), pack.split3_weight(rnd(N, K, seed=198, scale=0.1))
+    with _hipemu.emulated() as hip:
+        h32 = hip.layernorm(a, gam, bet, 1e-6, dtype=f32)[0]
+        hs = hip.layernorm(a, gam, bet, 1e-6, dtype="bf16x3")[0]
+        assert hs.dtype == torch.bfloat16 and hs.shape == (M, 3 * K) and torch.equal(hs, hip.split3(h32))
+        rs = hip.rmsnorm(a, gam, 1e-6, dtype="bf16x3")[0]
+        assert torch.equal(rs, hip.split3(hip.rmsnorm(a, gam, 1e-6, dtype=f32)[0]))
+        g_unf = hip.gemm(h32, w3, dtype=f32, bias=bias, act=C.ACT_GELU)                       # fp32 out, GELU in place
+        g_spl = hip.gemm(hs, w3, dtype=f32, bias=bias, act=C.ACT_GELU, a_presplit=True, out_split=True)
+        assert g_spl.dtype == torch.bfloat16 and torch.equal(g_spl, hip.split3(g_unf))
+        y_unf = hip.gemm(g_unf, w2s, dtype=f32, epilogue=C.EPI_RESID, resid=a.clone())
+        y_spl = hip.gemm(g_spl, w2s, dtype=f32, epilogue=C.EPI_RESID, resid=a.clone(), a_presplit=True)
+        assert torch.equal(y_unf, y_spl)
+        s_unf = hip.gemm(h32, wg3, dtype=f32, epilogue=C.EPI_SWIGLU)
+        s_spl = hip.gemm(hs, wg3, dtype=f32, epilogue=C.EPI_SWIGLU, a_presplit=True, out_split=True)
+        assert s_spl.shape == (M, 3 * N // 2) and torch.equal(s_spl, hip.split3(s_unf))
+        with pytest.raises(RuntimeError, match="SPLIT_OUT|out_split"):
+            hip.gemm(hs, w3, dtype=f32, epilogue=C.EPI_RESID, resid=resid.clone(), a_presplit=True, out_split=True)
 
 
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
