@@ -767,6 +767,14 @@ def _run(args, world, rank, device, dry):
                                                  "achieved": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1),
                                                  "frac": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / MFMA_PEAK[args.dtype], 4)}
                                              for k, v in sorted(s["shapes"].items())},
+                               # every GEMM (symbol, shape) that costs >= 1 ms per step, from the calibration step (events around EVERY launch: each launch
+                               # carries ~1 us of event overhead, so these fractions read a little low against the sampled `per_shape` above)
+                               "per_shape_all_ge_1ms": {f"{k} @ {shp}": {"launches": v2["launches"], "ms_per_step": round(v2["total_ms"], 3),
+                                                                          "avg_launch_us": round(v2["total_ms"] / v2["launches"] * 1e3, 2),
+                                                                          "achieved": round(v2["flops"] / (v2["total_ms"] * 1e-3) / 1e12, 1),
+                                                                          "frac": round(v2["flops"] / (v2["total_ms"] * 1e-3) / 1e12 / MFMA_PEAK[args.dtype], 4)}
+                                                        for k, v in sorted(cal.items(), key=lambda kv: -kv[1]["total_ms"])
+                                                        for shp, v2 in sorted(v["shapes"].items(), key=lambda kv: -kv[1]["total_ms"]) if v2["total_ms"] >= 1.0},
                                "all_gemm_kernels_one_step": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
                                                                  "tflops": round(v["flops"] / max(v["total_ms"], 1e-9) / 1e9, 1)}
                                                              for k, v in sorted(cal.items(), key=lambda kv: -kv[1]["total_ms"])}}

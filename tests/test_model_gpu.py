@@ -492,7 +492,7 @@ def test_full_size_configs_3_4_5_vs_reference(tag):
         samples["mask"] = mask
     sm = model.model.stllm_model
     res = {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16x3", "bf16"):   # exact verify, split verify (three bf16 MFMA products per Linear: the same 1e-2 bar), the timed dtype
         with runtime.use_dtype(mode):
             for m in (sm.visual_encoder, sm.Qformer.bert, model.model):
                 m.repack()
@@ -506,7 +506,7 @@ def test_full_size_configs_3_4_5_vs_reference(tag):
         mvm = f", loss_mvm {float(out.loss_mvm):.5f} vs {g['loss_mvm'][0]:.5f}" if cfg["use_mask"] else ""
         print(f"\n[{tag}_full {mode}] S={lg.shape[1]} logits max-abs err {err:.3e} (abs-max {g['logits_stats'][1]:.2f}), top-1 agreement {agree:.4f}, "
               f"loss {out.loss.item():.5f} vs {g['loss'][0]:.5f}{mvm}")
-        if mode == "fp32":
+        if mode in ("fp32", "bf16x3"):
             top = lg.topk(5, dim=-1)
             assert err <= 1e-2 and agree >= 0.99
             assert np.abs(top.values.numpy() - g["top_vals"]).max() <= 1e-2
