@@ -171,6 +171,13 @@ int stllm_gemm_bf16x3(const stllm_gemm_args* a, void* stream_) {
   STLLM_CHECK_ARG(need == 0 || (a->split_ws && aligned16(a->split_ws) && a->split_ws_bytes >= need),
                   "stllm_gemm(BF16X3): split_ws of %lld bytes needed (stllm_gemm_split_ws_bytes), %lld given", (long long)need, (long long)a->split_ws_bytes);
   STLLM_CHECK_ARG(a->epilogue != STLLM_EPI_SWIGLU || a->N % 64 == 0, "stllm_gemm(BF16X3, SWIGLU): N %% 64");
+  if (out_split) {   // (checked before anything is launched)
+    const int n_out = a->epilogue == STLLM_EPI_SWIGLU ? a->N / 2 : a->N;
+    STLLM_CHECK_ARG(a->ldo >= 3 * (int64_t)n_out && a->ldo % 4 == 0 && a->o_batch_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a->out) & 7) == 0,
+                    "stllm_gemm(BF16X3, STLLM_SPLIT_OUT): out = bf16 [M, ldo >= 3 x %d], 8-byte aligned", n_out);
+  } else {
+    STLLM_CHECK_ARG(a->ldo % 4 == 0 && a->o_batch_stride % 4 == 0, "stllm_gemm(BF16X3): fp32 output rows must be 16-byte aligned (ldo=%lld)", (long long)a->ldo);
+  }
   char* ws = reinterpret_cast<char*>(a->split_ws);
   int rc;
   stllm_gemm_args g = *a;
@@ -201,8 +208,6 @@ int stllm_gemm_bf16x3(const stllm_gemm_args* a, void* stream_) {
   float* out = reinterpret_cast<float*>(a->out);
   if (out_split) {
     uint16_t* o16 = reinterpret_cast<uint16_t*>(a->out);
-    const int n_out = a->epilogue == STLLM_EPI_SWIGLU ? a->N / 2 : a->N;
-    STLLM_CHECK_ARG(a->ldo >= 3 * (int64_t)n_out && a->ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a->out) & 7) == 0, "stllm_gemm(BF16X3, STLLM_SPLIT_OUT): out = bf16 [M, ldo >= 3 x %d]", n_out);
     if (a->epilogue == STLLM_EPI_SWIGLU)
       hipLaunchKernelGGL((post_split_rows_kernel<4>), grid, block, 0, stream, tmp, a->N, o16, a->ldo, a->o_rows_per_batch, a->o_batch_stride, a->M, a->N, 0);
     else

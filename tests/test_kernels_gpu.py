@@ -482,6 +482,18 @@ def test_gemm_w4_192_column_tiles(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
+@pytest.mark.parametrize("M,D", [(4112, 1408), (576, 4096), (37, 768)])
+def test_norms_write_the_split_image(hip, M, D):
+    """stllm_layernorm / stllm_rmsnorm with dtype STLLM_BF16X3: out_t = bf16 [M, 3 D] = (hi | hi | lo) of the fp32 result, bit-identical to
+    splitting the fp32 output afterwards (both norm kernels: one wave per row and one workgroup per row)."""
+    x = T("x3.norm.x", (M, D), 1.5).cuda()
+    gam, bet = (T("x3.norm.g", (D,), 0.2) + 1.0).cuda(), T("x3.norm.b", (D,), 0.1).cuda()
+    ln32 = hip.layernorm(x, gam, bet, 1e-6, dtype="fp32")[0]
+    assert torch.equal(hip.layernorm(x, gam, bet, 1e-6, dtype="bf16x3")[0], hip.split3(ln32))
+    rms32 = hip.rmsnorm(x, gam, 1e-6, dtype="fp32")[0]
+    assert torch.equal(hip.rmsnorm(x, gam, 1e-6, dtype="bf16x3")[0], hip.split3(rms32))
+
+
 BF16X3_CASES = [  # (name, M, N, K, epilogue): the benchmarked GEMM shapes of the ViT and of the Llama prefill + a ragged small one
     ("vit_qkv", 4112, 4224, 1408, "store"), ("vit_proj", 4112, 1408, 1408, "resid"), ("vit_fc1", 4112, 6144, 1408, "gelu"),
     ("vit_fc2", 4112, 1408, 6144, "resid"), ("llm_qkv", 576, 12288, 4096, "rope"), ("llm_gu", 576, 22016, 4096, "swiglu"),
@@ -528,6 +540,16 @@ def test_gemm_bf16x3_split_mode(hip, name, M, N, K, epi):
         ref = v.reshape(M, N)
     assert got.dtype == torch.float32
     check(got, ref, 2e-5, f"bf16x3 {name}")
+    # chained form (what the stack entry points issue): A already split, GELU / SwiGLU leave as the split image — the same bits as the unfused calls
+    a3 = hip.split3(ad)
+    assert torch.equal(a3[:, :K], ad.to(torch.bfloat16)) and torch.equal(a3[:, 2 * K:], (ad - ad.to(torch.bfloat16).float()).to(torch.bfloat16))
+    if epi in ("gelu", "relu"):
+        act = hip.ACT_GELU if epi == "gelu" else hip.ACT_RELU
+        assert torch.equal(hip.gemm(a3, w3, dtype="fp32", bias=bd, act=act, a_presplit=True, out_split=True), hip.split3(got))
+    elif epi == "swiglu":
+        assert torch.equal(hip.gemm(a3, w3, dtype="fp32", epilogue=hip.EPI_SWIGLU, a_presplit=True, out_split=True), hip.split3(got))
+    elif epi == "store":
+        assert torch.equal(hip.gemm(a3, w3, dtype="fp32", bias=bd, a_presplit=True), got)
     plain = hip.gemm(ad.to(torch.bfloat16), w.cuda().to(torch.bfloat16), dtype="bf16", out_f32=True)
     e3 = (hip.gemm(ad, w3, dtype="fp32").double().cpu() - acc).abs().max().item()
     e1 = (plain.double().cpu() - acc).abs().max().item()
