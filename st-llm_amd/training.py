@@ -35,10 +35,10 @@ def _kgran(dt):
     return 32 if dt == torch.float32 else 64
 
 
-def linear_bwd(dy, x, w, dt, *, need_dx=True, dx_resid=None, dx_f32=False, need_dw=True):
+def linear_bwd(dy, x, w, dt, *, need_dx=True, dx_resid=None, dx_f32=False, need_dw=True, dw_out=None):
     """y = x @ w^T.  dy [M,N], x [M,K], w [N,K] — all in the compute dtype `dt`.
     Returns (dx, dw): dx [M,K] (compute dtype, or fp32 when dx_f32; accumulated into `dx_resid` fp32 [M,K] when given),
-    dw fp32 [N,K]."""
+    dw fp32 [N,K] — written straight into `dw_out` (a contiguous fp32 [N,K], e.g. the optimizer's slice of its flat gradient buffer) when given."""
     dx = dw = None
     if need_dx:
         wt = hip.transpose(w, pad=_kgran(dt))                    # [K, N]
@@ -49,26 +49,32 @@ def linear_bwd(dy, x, w, dt, *, need_dx=True, dx_resid=None, dx_f32=False, need_
     if need_dw:
         dyt = hip.transpose(dy, pad=_kgran(dt))                  # [N, Mp]
         xt = hip.transpose(x, pad=_kgran(dt))                    # [K, Mp]
-        dw = hip.gemm(dyt, xt, dtype=dt, out_f32=True)           # [N, K]
+        if dw_out is not None and (tuple(dw_out.shape) != (dy.shape[1], x.shape[1]) or not dw_out.is_contiguous()):
+            dw_out = None                                        # a padded weight (lm_head of a 32001-token vocabulary): the caller slices and copies
+        dw = hip.gemm(dyt, xt, dtype=dt, out_f32=True, out=dw_out)   # [N, K]
     return dx, dw
 
 
-def unpack_qkv_grad(dw, n_heads):
-    """inverse of pack.llama_qkv on a [3D, D] gradient -> (dq, dk, dv) in the reference's row order"""
+def unpack_qkv_grad(dw, n_heads, out=(None, None, None)):
+    """inverse of pack.llama_qkv on a [3D, D] gradient -> (dq, dk, dv) in the reference's row order; `out`: contiguous fp32 [D, D]
+    destinations (the optimizer's gradient slices) or None each"""
     D = dw.shape[0] // 3
     perm = pack.rope_head_perm(n_heads, D // n_heads, dw.device)
-    dq = torch.empty_like(dw[:D])
-    dk = torch.empty_like(dw[:D])
+    dq, dk, dv = (torch.empty_like(dw[:D]) if o is None else o for o in out)
     dq[perm] = dw[:D]
     dk[perm] = dw[D:2 * D]
-    return dq, dk, dw[2 * D:].clone()
+    dv.copy_(dw[2 * D:])
+    return dq, dk, dv
 
 
-def unpack_gate_up_grad(dw):
-    """inverse of pack.llama_gate_up on a [2I, D] gradient -> (dgate, dup)"""
+def unpack_gate_up_grad(dw, out=(None, None)):
+    """inverse of pack.llama_gate_up on a [2I, D] gradient -> (dgate, dup); `out` as in unpack_qkv_grad"""
     n2, k = dw.shape
     v = dw.view(n2 // 64, 2, 32, k)
-    return v[:, 0].reshape(n2 // 2, k).contiguous(), v[:, 1].reshape(n2 // 2, k).contiguous()
+    dg, du = (torch.empty((n2 // 2, k), device=dw.device, dtype=dw.dtype) if o is None else o for o in out)
+    dg.view(n2 // 64, 32, k).copy_(v[:, 0])
+    du.view(n2 // 64, 32, k).copy_(v[:, 1])
+    return dg, du
 
 
 # ---- the LLM: forward that keeps activations, and its backward ---------------------------------------------------------
@@ -122,9 +128,16 @@ def llama_forward_taped(lm, inputs_embeds, attention_mask=None):
     return t.h32.view(B, S, D), t.h16, t
 
 
-def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model."):
+def _no_sink(name):
+    return None
+
+
+def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model.", sink=_no_sink):
     """Backward of llama_forward_taped.  d_h16: gradient w.r.t. the compute-dtype output of model.norm ([M,D], compute dtype),
-    d_h32: w.r.t. its fp32 twin ([M,D] fp32); either may be None.  Returns (d_inputs_embeds fp32 [M,D], grads dict)."""
+    d_h32: w.r.t. its fp32 twin ([M,D] fp32); either may be None.  Returns (d_inputs_embeds fp32 [M,D], grads dict).
+    sink(name) -> the fp32 destination of that parameter's gradient (AdamW.grad_sink: a slice of the flat gradient buffer) or None:
+    the 25.8 GB of layer weight gradients of a 7B step are then written once, by the wgrad GEMM / the un-permutation, instead of being
+    produced in a temporary and copied by AdamW.step."""
     cfg = lm.config
     dt = runtime.compute_dtype()
     packs = lm.pack(dt)
@@ -149,15 +162,16 @@ def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model."):
         lp = f"{prefix}layers.{li}."
         dx16 = hip.cast_rows(dx, dt)
         # x2 = x1 + g @ Wdown^T
-        dg, dw = linear_bwd(dx16, rec["g"], pk["wdown"], dt)
+        dg, dw = linear_bwd(dx16, rec["g"], pk["wdown"], dt, dw_out=sink(lp + "mlp.down_proj.weight"))
         grads[lp + "mlp.down_proj.weight"] = dw
         dgu = hip.swiglu_bwd(rec["gu"], dg)
         dh2, dw = linear_bwd(dgu, rec["h2"], pk["wgu"], dt)
-        grads[lp + "mlp.gate_proj.weight"], grads[lp + "mlp.up_proj.weight"] = unpack_gate_up_grad(dw)
+        grads[lp + "mlp.gate_proj.weight"], grads[lp + "mlp.up_proj.weight"] = unpack_gate_up_grad(
+            dw, (sink(lp + "mlp.gate_proj.weight"), sink(lp + "mlp.up_proj.weight")))
         grads[lp + "post_attention_layernorm.weight"] = hip.rmsnorm_bwd(rec["x1"], pk["ln2"], cfg.rms_norm_eps, dh2, dx, accumulate=True)
         # x1 = x0 + a @ Wo^T          (dx is now dL/dx1)
         dx16 = hip.cast_rows(dx, dt)
-        da, dw = linear_bwd(dx16, rec["a"], pk["wo"], dt)
+        da, dw = linear_bwd(dx16, rec["a"], pk["wo"], dt, dw_out=sink(lp + "self_attn.o_proj.weight"))
         grads[lp + "self_attn.o_proj.weight"] = dw
         qkv = rec["qkv"]
         dqkv = torch.empty_like(qkv)
@@ -166,7 +180,8 @@ def llama_backward(lm, tape, d_h16=None, d_h32=None, prefix="model."):
         hip.rope_bwd(dqkv, tape.cos, tape.sin, rope_seq=S, rope_cols=2 * D)
         dh1, dw = linear_bwd(dqkv, rec["h1"], pk["wqkv"], dt)
         a = lp + "self_attn."
-        grads[a + "q_proj.weight"], grads[a + "k_proj.weight"], grads[a + "v_proj.weight"] = unpack_qkv_grad(dw, H)
+        grads[a + "q_proj.weight"], grads[a + "k_proj.weight"], grads[a + "v_proj.weight"] = unpack_qkv_grad(
+            dw, H, (sink(a + "q_proj.weight"), sink(a + "k_proj.weight"), sink(a + "v_proj.weight")))
         grads[lp + "input_layernorm.weight"] = hip.rmsnorm_bwd(rec["x0"], pk["ln1"], cfg.rms_norm_eps, dh1, dx, accumulate=True)
     return dx, grads
 
@@ -182,8 +197,10 @@ def _mark(name):
         PHASES.append((name, ev))
 
 
-def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
+def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None, sink=None):
     """model: STLLMForCausalLM.  Returns (loss fp32 scalar tensor, loss_mvm or None, grads {reference name: fp32 tensor}).
+    sink: AdamW.grad_sink() — the LLM's weight gradients (lm_head, 32 x q/k/v/o/gate/up/down, the embedding table) are then produced IN the
+    optimizer's flat gradient buffer and the returned tensors alias it (train_step does this); None: every gradient is its own tensor.
     On the eva_btadapter_g backbone the reference also trains the `visual_encoder.BTAdapter*` parameters (st_llm.py:257-261): their
     gradient is carried back through llama_proj, the frozen Q-Former and ln_vision into the adapter branch (training_vision.py);
     freeze_btadapter=True skips that and treats the adapter as frozen.  drop_path: the adapter blocks' train-mode stochastic depth as
@@ -220,7 +237,8 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
     rows = hip.cross_entropy_rows(logits[:, :V], lab)
     loss = rows.sum() / n_valid
     dlogits = hip.cross_entropy_bwd(logits, lab, 1.0 / n_valid, dtype=dt, vocab=V)
-    d_h16, dw = linear_bwd(dlogits, h16, Wlm, dt)
+    sink = sink or _no_sink
+    d_h16, dw = linear_bwd(dlogits, h16, Wlm, dt, dw_out=sink("lm_head.weight"))
     grads["lm_head.weight"] = dw[:V]
     # ---- MVM branch (st_llm.py:71-91) -------------------------------------------------------------------------------
     loss_mvm = None
@@ -262,12 +280,13 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None):
         hip.scatter_add_rows(da_in, rows_a, d_h32)
     # ---- the LLM ----------------------------------------------------------------------------------------------------
     _mark("lm_head + losses (+ MVM target pass)")
-    d_emb, g_llm = llama_backward(lm, lt, d_h16, d_h32)
+    d_emb, g_llm = llama_backward(lm, lt, d_h16, d_h32, sink=sink)
     _mark("LLM backward")
     grads.update(g_llm)
     # ---- token-block assembly: gather_rows^T (visual rows | embedding-table rows) -------------------------------------
     d_vis = torch.zeros((tape["vis_rows"], D), device=dev, dtype=torch.float32)
-    d_table = torch.zeros_like(lm.embed_tokens.weight, dtype=torch.float32)
+    d_table = sink("model.embed_tokens.weight")
+    d_table = torch.zeros_like(lm.embed_tokens.weight, dtype=torch.float32) if d_table is None else d_table.zero_()
     hip.scatter_add_rows(d_emb, tape["gather_idx"][0], d_vis, d_table)        # ([1], the un-masked assembly, carries no gradient)
     grads["model.embed_tokens.weight"] = d_table
     # ---- pooling (st_llm.py:463-478) --------------------------------------------------------------------------------
@@ -362,6 +381,18 @@ class AdamW:
         self.m = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self.v = torch.zeros(self.shard, device=dev, dtype=torch.float32)
         self.gflat = torch.zeros(self.n_pad, device=dev, dtype=torch.float32)
+        self._slot = {name: (off, p.shape) for name, off, p in zip(self.names, self.offsets, self.params)}
+
+    def grad_sink(self):
+        """name -> this parameter's slice of the flat gradient buffer, shaped like the parameter (None for names that are not optimised):
+        a producer that writes a gradient there (training.loss_and_grads(sink=...)) saves step() the copy."""
+        def sink(name):
+            slot = self._slot.get(name)
+            if slot is None:
+                return None
+            off, shape = slot
+            return self.gflat[off: off + shape.numel()].view(shape)
+        return sink
 
     def step(self, grads):
         """grads: {name: fp32 tensor} of THIS rank's micro-batch.  Returns the global gradient norm (before clipping).
@@ -375,7 +406,7 @@ class AdamW:
             present.append(g is not None)
             if g is None:
                 self.gflat[off: off + p.numel()].zero_()
-            else:
+            elif not (g.is_contiguous() and g.numel() == p.numel() and g.data_ptr() == self.gflat.data_ptr() + 4 * off):   # else: produced in place (grad_sink)
                 self.gflat[off: off + p.numel()] = g.reshape(-1)
         lo = self.rank * self.shard
         if self.world > 1:
@@ -463,7 +494,7 @@ def trainable_state_dict(model):
 
 def train_step(model, samples, optimizer, freeze_btadapter=False, drop_path=None):
     """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1)."""
-    loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter, drop_path)
+    loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter, drop_path, sink=optimizer.grad_sink())
     norm = optimizer.step(grads)
     invalidate_packed(model)
     if loss.is_cuda:   # optimizer.step() read the gradient norm back: the stream is idle, check the split-K exchanges of this step

@@ -145,6 +145,36 @@ def test_mean_pooling_backward_and_one_optimizer_step():
     assert l1.item() < l0.item() - 0.05, (l0.item(), l1.item())
 
 
+def test_gradients_produced_in_the_optimizer_buffer_are_the_same_gradients():
+    """train_step hands AdamW.grad_sink() to loss_and_grads: the LLM's weight gradients (lm_head, q/k/v/o/gate/up/down of every layer, the
+    embedding table) are written by the wgrad GEMMs / the un-permutations INTO the flat gradient buffer.  Same bits as the stand-alone tensors,
+    the returned tensors alias the buffer, step() finds them in place (and still copies the rest), and a second step overwrites them."""
+    import _cpu_backend
+    from test_host_orchestration_cpu import CFGS, build, make_inputs
+    from stllm_amd import runtime, training
+    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=2)
+    samples, _ = make_inputs(2, 4, False)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        _, _, want = training.loss_and_grads(model, samples)
+        opt = training.AdamW(list(training.trainable_parameters(model)), lr=1e-3, max_grad_norm=1.0)
+        opt.gflat.fill_(float("nan"))                       # whatever is not written in place must arrive by step()'s copy
+        _, _, got = training.loss_and_grads(model, samples, sink=opt.grad_sink())
+        assert set(got) == set(want)
+        lo, hi = opt.gflat.data_ptr(), opt.gflat.data_ptr() + 4 * opt.gflat.numel()
+        in_place = {n for n, g in got.items() if lo <= g.data_ptr() < hi}
+        llm = {n for n in want if n.endswith("_proj.weight") and ".layers." in n} | {"lm_head.weight", "model.embed_tokens.weight"}
+        assert in_place == llm, in_place ^ llm
+        for n in want:
+            assert torch.equal(got[n], want[n]), n
+        norm = opt.step(got)
+        for n, off, p in zip(opt.names, opt.offsets, opt.params):
+            assert torch.equal(opt.gflat[off: off + p.numel()].view(p.shape), want[n]), n
+        assert abs(norm - float(torch.sqrt(sum((g.double() ** 2).sum() for g in want.values())))) <= 1e-4 * norm
+        l1, _, _ = training.train_step(model, samples, opt)  # the second step: every slot overwritten, nothing stale, nothing NaN
+        assert torch.isfinite(opt.gflat).all() and torch.isfinite(l1)
+    assert opt.grad_sink()("no.such.parameter") is None
+
+
 def test_btadapter_backbone_end_to_end_matches_reference():
     """The reference's main training config (config/instructblipbase_stllm_qa.yaml: eva_btadapter_g backbone, Q-Former text input,
     video_input all, dynamic masking + MVM loss): loss_and_grads carries the gradient through llama_proj, the

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--backbone", default="eva_clip_g", choices=["eva_clip_g", "eva_btadapter_g"],
                     help="eva_btadapter_g = the reference's main training config: the BTAdapter* parameters train too")
+    ap.add_argument("--no-sink", action="store_true", help="gradients as stand-alone tensors, copied by AdamW.step (the pre-round-4 path)")
     ap.add_argument("--text", action="store_true", help="Q-Former text input (instructblip_* model types)")
     a = ap.parse_args()
     from stllm_amd import runtime, synth, training
@@ -44,7 +45,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.time()
             training.PHASES = []
-            loss, loss_mvm, grads = training.loss_and_grads(model, samples)
+            loss, loss_mvm, grads = training.loss_and_grads(model, samples, sink=None if a.no_sink else opt.grad_sink())
             torch.cuda.synchronize()
             t1 = time.time()
             marks, training.PHASES = training.PHASES, None
