@@ -45,6 +45,7 @@ StllmOptions& stllm_options() {
     o.attn_bwd_valu = env_int("STLLM_ATTN_BWD_VALU", 0);
     o.norm_fast = env_int("STLLM_NORM_FAST", 1);
     o.gemm_w4_odd = env_int("STLLM_GEMM_W4_ODD", 1);
+    o.gemm_w4_wide = env_int("STLLM_GEMM_W4_WIDE", 1);
     o.attn_f32_mfma = env_int("STLLM_ATTN_F32_MFMA", 1);
     init = true;
   }
@@ -65,6 +66,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "attn_bwd_valu")) { o.attn_bwd_valu = value; return STLLM_OK; }
   if (!strcmp(key, "norm_fast")) { o.norm_fast = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_odd")) { o.gemm_w4_odd = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_w4_wide")) { o.gemm_w4_wide = value; return STLLM_OK; }
   if (!strcmp(key, "attn_f32_mfma")) { o.attn_f32_mfma = value; return STLLM_OK; }
   stllm_set_error("stllm_set_option: unknown key %s", key);
   return STLLM_ERR_UNSUPPORTED;

@@ -941,7 +941,7 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
   int split = 1;
   const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape, &split);
-  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33) { *shape = g_w4_mode; return true; }
+  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24) { *shape = g_w4_mode; return true; }
   if (g_w4_mode == 1) return true;
   if (g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_p8_mode == 0) return false;   // a forced / disabled kernel family (tests / experiments) wins
   // Round 2, first version (2-buffer LDS ring): no gain inside bench.py, where the weights come from HBM (proj + fc2 5.39 ms per
@@ -961,7 +961,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
   if constexpr (!Elem<T>::kIsF32) {
     const StllmOptions& o_ = stllm_options();   // this thread's options: env parsed once, before any decision below
     const int gemv_mode = o_.gemm_gemv, g_sk_mode = o_.gemm_sk, g_p8_mode = o_.gemm_p8, g_w4_mode = o_.gemm_w4;
-    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33;   // tests / experiments
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
     if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
       const int rc = a->epilogue != STLLM_EPI_PATCH ? stllm_gemv_launch(a->dtype, a->epilogue, p, stream) : STLLM_ERR_UNSUPPORTED;
@@ -985,6 +985,14 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       bool w4_go = w4_wanted(p, heavy | thin_bit, &shape, p8_est);
       if (!w4_go && g_w4_mode == 3 && a->epilogue == STLLM_EPI_ROPE && p.M < 1024 && p.ws != nullptr &&
           p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) { shape = 32; w4_go = true; }
+      // Llama prefill qkv (ROPE epilogue, a few hundred rows): the 128 x 256 one-wave tile when its tiles make ONE well-filled round and nothing is
+      // exchanged — 576 x 12288 x 4096: 5 x 48 = 240 tiles, 68.8-72 us against 80-82 us on the 128 x 128 kernel (480 tiles = 1.9 rounds) in the
+      // harness, profiles/r04_w4_128x256_qkv.md (the vendor library picks the same macro tile for this shape)
+      if (!w4_go && (g_w4_mode == -1 || g_w4_mode == 2 || g_w4_mode == 3) && o_.gemm_w4_wide && a->epilogue == STLLM_EPI_ROPE && !forced_tiles && p.ws != nullptr &&
+          p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4 && p.N % 256 == 0) {
+        const int t24 = ((p.M + 127) / 128) * (p.N / 256);
+        if (t24 >= 192 && t24 <= 256) { shape = 24; w4_go = true; }
+      }
       if (w4_go) {
         const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
                                                       : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);

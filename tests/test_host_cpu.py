@@ -67,7 +67,7 @@ def test_w4_gemm_schedule_invariants():
     from stllm_amd import hip
     shapes_ = [(4112, 4224, 1408), (4112, 6144, 1408), (4112, 1408, 6144), (576, 12288, 4096), (576, 22016, 4096), (576, 4096, 11008),
                (4096, 4096, 4096), (1, 128, 64), (300, 384, 192), (100000, 256, 64), (3072, 8192, 1408)]
-    for shape, rows, cols in ((34, 192, 256), (44, 256, 256), (32, 192, 128), (42, 256, 128), (43, 256, 192), (33, 192, 192)):
+    for shape, rows, cols in ((34, 192, 256), (44, 256, 256), (32, 192, 128), (42, 256, 128), (43, 256, 192), (33, 192, 192), (24, 128, 256)):
         for M, N, K in shapes_:
             for heavy in (0, 1, 2):
                 q, r, s, cap, est = hip.gemm_w4_plan(M, N, K, heavy, shape)
@@ -90,6 +90,7 @@ def test_w4_gemm_schedule_invariants():
     # round 3: 192-column tiles (16-bit STORE epilogues only)
     assert hip.gemm_w4_plan(4112, 6144, 1408, 2 | 8, 43)[:3] == (2, 0, 1)     # ViT fc1: 16 x 32 tiles of 256 x 192 = TWO whole rounds (+ 16 thin rows)
     assert hip.gemm_w4_plan(4112, 4224, 1408, 8, 33)[:3] == (1, 228, 1)       # ViT qkv: 22 x 22 tiles of 192 x 192 = 1.9 rounds, no K split
+    assert hip.gemm_w4_plan(576, 12288, 4096, 0, 24)[:3] == (0, 240, 1)        # round 4, Llama prefill qkv: 5 x 48 tiles of 128 x 256 = ONE partial round, nothing exchanged
     with pytest.raises(RuntimeError):
         hip.gemm_w4_plan(576, 4096, 4096, 0, 35)
 

@@ -415,11 +415,11 @@ W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 
              (528, 768, 1408), (596, 384, 256)]   # the last two: a tail of 16 rows past 256-row tiles / 20 rows past 192-row tiles (thin-tail path)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 42])
+@pytest.mark.parametrize("shape", [32, 34, 42, 24])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 def test_gemm_w4(hip, dtype, shape, M, N, K):
-    """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128 tiles): whole rounds, remainder-first K-split
+    """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128 and — round 4 — 128 x 256 tiles): whole rounds, remainder-first K-split
     with the end-of-launch reduction, M / N tails (256 x 256 retired in round 3: a forced 44 falls back to the other kernels), (incl. the thin-tail rows computed outside the tile grid), fp32 / GELU / residual
     epilogues, epoch flags, determinism."""
     hip.set_option("gemm_w4", shape)
@@ -624,7 +624,7 @@ def test_gemm_w4_thin_tail_with_two_level_rows(hip, shape, n_seq):
         hip.set_option("gemm_w4", -1)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 42])
+@pytest.mark.parametrize("shape", [32, 34, 42, 24])
 def test_gemm_w4_swiglu_rope_rows(hip, shape):
     from stllm_amd import pack
     dtype = "bf16"
@@ -666,6 +666,35 @@ def test_gemm_w4_swiglu_rope_rows(hip, shape):
         assert float(outb.view(N_, S2, Nout)[:, Q:].abs().max()) == 0.0
     finally:
         hip.set_option("gemm_w4", -1)
+
+
+def test_llama_prefill_qkv_runs_on_the_128x256_tile(hip):
+    """round 4: a ROPE-epilogue GEMM whose 128 x 256 tiles make one round of 192..256 tiles (Llama qkv at 385..640 rows) is dispatched to the
+    one-wave kernel's 128 x 256 tile (option gemm_w4_wide, default on); other row counts and the switched-off option keep the 128 x 128 kernel.
+    Same numbers either way (the epilogue arithmetic is the same; 1 ulp of the 16-bit output at most)."""
+    from stllm_amd import pack
+    dtype = "bf16"
+    H, D, K = 32, 128, 4096
+    wq, _ = rnd("q24.wq", (H * D, K), dtype, 0.02)
+    wk, _ = rnd("q24.wk", (H * D, K), dtype, 0.02)
+    wv, _ = rnd("q24.wv", (H * D, K), dtype, 0.02)
+    w = pack.llama_qkv(wq, wk, wv, dtype, n_heads=H)
+    for S, want in ((576, True), (400, True), (640, True), (641, False), (384, False), (150, False)):
+        a, _ = rnd(f"q24.a{S}", (S, K), dtype)
+        cos, sin = pack.rope_tables(S)
+        kw = dict(dtype=dtype, epilogue=hip.EPI_ROPE, rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D)
+        out = hip.gemm(a, w, **kw)
+        name = hip.lib().stllm_last_kernel().decode()
+        assert name.startswith("gemm_w4_kernel<bf16_t,2,4,ROPE") == want, (S, name)
+        hip.set_option("gemm_w4_wide", 0)
+        try:
+            ref = hip.gemm(a, w, **kw)
+            assert "gemm_w4_kernel<bf16_t,2,4" not in hip.lib().stllm_last_kernel().decode()
+        finally:
+            hip.set_option("gemm_w4_wide", 1)
+        d = (out.float() - ref.float()).abs()
+        assert float((d / ref.float().abs().clamp(min=1.0)).max()) <= 2 ** -7, (S, float(d.max()))
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
 
 
 def test_gemm_phased_auto_dispatch(hip):

@@ -26,11 +26,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--vendor", action="store_true", help="also time torch's library GEMM (hipBLASLt, then rocBLAS) on the same operands: plain "
+                    "A @ W^T -> 16-bit, no epilogue — a calibration of what the vendor kernels reach on these shapes, never a product path")
     a = ap.parse_args()
     td = hip.torch_dtype(a.dtype)
     only = set(a.only.split(",")) if a.only else None
     total_ms = 0.0
     total_fl = 0.0
+    vendor_ms = {}
     for name, M, N, K, epi, per_clip in SHAPES:
         if only and name not in only:
             continue
@@ -57,7 +60,24 @@ def main():
         fl = 2.0 * M * N * K
         total_ms += ms * per_clip; total_fl += fl * per_clip
         print(f"{name:9s} M={M:5d} N={N:6d} K={K:6d} {epi:8s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF   x{per_clip:2d} = {ms * per_clip:6.3f} ms  [{hip.lib().stllm_last_kernel().decode()}]")
+        if a.vendor:
+            Wv = W[:, :K].contiguous()
+            for libname in ("hipblaslt", "cublas"):     # torch's name for rocBLAS on ROCm
+                try:
+                    torch.backends.cuda.preferred_blas_library(libname)
+                    o = torch.empty(M, N, device="cuda", dtype=td)
+                    for _ in range(3): torch.matmul(A, Wv.t(), out=o)
+                    s.record()
+                    for _ in range(a.iters): torch.matmul(A, Wv.t(), out=o)
+                    e.record(); torch.cuda.synchronize()
+                    vms = s.elapsed_time(e) / a.iters
+                    vendor_ms[libname] = vendor_ms.get(libname, 0.0) + vms * per_clip
+                    print(f"    {'rocblas' if libname == 'cublas' else libname:9s} plain store {vms * 1e3:8.1f} us  {fl / vms / 1e9:7.1f} TF   ours / vendor time = {ms / vms:5.2f}")
+                except Exception as ex:   # noqa: BLE001
+                    print(f"    {libname}: {type(ex).__name__}: {ex}")
     print(f"total GEMM time per clip: {total_ms:.3f} ms  ({total_fl / total_ms / 1e9:.1f} TF/s average)")
+    for libname, v in vendor_ms.items():
+        print(f"   {'rocblas' if libname == 'cublas' else libname} (plain store, no epilogue): {v:.3f} ms  ({total_fl / v / 1e9:.1f} TF/s average)")
 
 
 if __name__ == "__main__":

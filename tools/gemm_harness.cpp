@@ -107,7 +107,9 @@ int main(int argc, char** argv) {
     const int No = c.epi == STLLM_EPI_SWIGLU ? N / 2 : N;
     const bool f32o = c.epi == STLLM_EPI_RESID || c.of32;
     const size_t oes = f32o ? 4 : 2;
-    std::vector<uint16_t> hA((size_t)M * K), hW((size_t)N * K);
+    const int ldpad = getenv("HARNESS_LDPAD") ? atoi(getenv("HARNESS_LDPAD")) : 0;   // elements added to the row stride of A and W (channel-aliasing experiments: K = 4096 rows are 8 KiB apart)
+    const int LD = K + ldpad;
+    std::vector<uint16_t> hA((size_t)M * LD), hW((size_t)N * LD);
     for (auto& v : hA) v = f2bf(urand());
     for (auto& v : hW) v = f2bf(urand() * 0.05f);
     std::vector<float> hb(N), hres((size_t)M * N), hcos(576 * 64), hsin(576 * 64);
@@ -144,7 +146,7 @@ int main(int argc, char** argv) {
     stllm_gemm_args a;
     memset(&a, 0, sizeof(a));
     a.dtype = STLLM_BF16; a.epilogue = c.epi; a.act = c.act; a.out_is_f32 = c.of32;
-    a.A = dA; a.lda = K; a.W = dW; a.ldw = K; a.bias = db; a.ldo = No;
+    a.A = dA; a.lda = LD; a.W = dW; a.ldw = LD; a.bias = db; a.ldo = No;
     a.resid = dres; a.ldr = N; a.aux0 = dcos; a.aux1 = dsin; a.rope_seq = 576; a.rope_cols = (N / 3) * 2 / 128 * 128;
     a.M = M; a.N = N; a.K = K; a.workspace = ws; a.workspace_bytes = ws_bytes;
 
