@@ -906,6 +906,20 @@ int dispatch_store(const GemmParams& p, hipStream_t stream) {
 // Phased kernel (gemm_p8.inc): 16-bit dtypes, needs the workspace.  mode 1 / 3 / 4: always (cost model / 192 / 256 rows);
 // auto: when its cost model beats the estimate for the 128x128 kernels by a margin (both calibrated on MI355X, see
 // profiles/r01_gemm_p8.md; a wrong guess near the margin costs a few percent either way).
+// estimate for the 128x128 / 64x64 persistent kernels (the model p8_wanted compares with)
+static float old_kernels_estimate_us(const GemmParams& p) {
+  const int nk = p.K / 64;
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
+  if (t128 < 192) {   // 64x64 tiles, 4 workgroups per CU.  Round 4 re-calibration (profiles/r04_gemm64_ring4_harness.log, r04_gemm_vs_vendor.log): 6.9-8.4 us at
+    // 12 K units, 17.7 at 48 (<= 256 tiles: one tile per CU slot), 54-68 us for the 576 tiles x 64 units of the Llama o_proj shape — the old
+    // 5 + 0.55 nk over-estimated the short-K / few-tile case by 13 us and sent the Q-Former's 512 x 768 x 3072 residual GEMM to the phased
+    // kernel's K-split (27.8 us, 12 launches per step) although this kernel runs it in 18-19
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * (p.N / 64);
+    return 3.5f + nk * 0.30f * (float)((t64 + 255) / 256);
+  }
+  return 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
+}
+
 static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   const int g_p8_mode = stllm_options().gemm_p8, g_sk_mode = stllm_options().gemm_sk;
   if (g_p8_mode == 0 || p.ws == nullptr) return false;
@@ -914,20 +928,7 @@ static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
   if (g_p8_mode == 3 || g_p8_mode == 4) { *miw = g_p8_mode; return true; }
   if (g_p8_mode == 1) return true;
   if (g_sk_mode >= 1) return false;   // a forced stream-K tile (tests / experiments) wins over the automatic choice
-  const int nk = p.K / 64;
-  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
-  float old_us;
-  if (t128 < 192) old_us = 5.0f + nk * 0.55f;                       // 64x64 tiles, 4 workgroups per CU
-  else old_us = 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
-  return est < 0.93f * old_us;
-}
-
-// estimate for the 128x128 / 64x64 persistent kernels (the model p8_wanted compares with)
-static float old_kernels_estimate_us(const GemmParams& p) {
-  const int nk = p.K / 64;
-  const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
-  if (t128 < 192) return 5.0f + nk * 0.55f;                       // 64x64 tiles, 4 workgroups per CU
-  return 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
+  return est < 0.93f * old_kernels_estimate_us(p);
 }
 
 // One-wave-per-SIMD kernel (gemm_w4.inc): same eligibility as the phased kernel.  mode 1 / 32 / 34 / 44: always (cost model /

@@ -152,7 +152,7 @@ def test_gradients_produced_in_the_optimizer_buffer_are_the_same_gradients():
     import _cpu_backend
     from test_host_orchestration_cpu import CFGS, build, make_inputs
     from stllm_amd import runtime, training
-    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=2)
+    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=1)
     samples, _ = make_inputs(2, 4, False)
     with _cpu_backend.installed(), runtime.use_dtype("fp32"):
         _, _, want = training.loss_and_grads(model, samples)

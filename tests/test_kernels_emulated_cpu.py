@@ -343,7 +343,7 @@ def test_emulated_forward_norms(dtype):
 
 
 @pytest.mark.skipif(_hipemu.ON_DEVICE, reason="covered by tests/test_kernels_gpu.py on the device")
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16])   # (an A/B switch that is off by default: one dtype keeps the CPU suite short; the fp32 store path is the one-row kernel's)
 def test_emulated_norms_two_rows_per_wave(dtype):
     """option norm_fast = 2: two rows per wave for many short rows (an odd row count: the last wave's second row is a clamped duplicate
     that must not be stored)"""

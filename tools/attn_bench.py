@@ -7,6 +7,10 @@ from stllm_amd import hip
 
 CASES = [("vit", 16, 16, 257, 257, 88, False, 39), ("llama", 1, 32, 576, 576, 128, True, 32), ("llama_b4", 4, 32, 576, 576, 128, True, 32),
          ("qf_self", 16, 12, 32, 32, 64, False, 12), ("qf_cross", 16, 12, 32, 257, 64, False, 6)]
+if "--probe" in sys.argv:   # how does the Llama prefill kernel's time scale with the keys a workgroup walks / the workgroups in flight?  (non-causal: every workgroup alike)
+    CASES += [("nc_k128", 1, 32, 576, 128, 128, False, 0), ("nc_k256", 1, 32, 576, 256, 128, False, 0), ("nc_k288", 1, 32, 576, 288, 128, False, 0),
+              ("nc_k576", 1, 32, 576, 576, 128, False, 0), ("nc_k288_h51", 1, 51, 576, 288, 128, False, 0), ("nc_k288_h64", 1, 64, 576, 288, 128, False, 0),
+              ("c_s288", 1, 32, 288, 288, 128, True, 0), ("c_s288_h64", 1, 64, 288, 288, 128, True, 0)]
 for name, B, H, Sq, Skv, D, causal, per_clip in CASES:
     dt = torch.bfloat16
     if Sq == Skv:
