@@ -18,7 +18,8 @@ SHAPES = [  # name, M, N, K, epilogue, launches per clip
     ("qf_ffn1", 512, 3072, 768, "gelu", 12), ("qf_ffn2", 512, 768, 3072, "resid", 12),
     ("llm_qkv", 576, 12288, 4096, "rope", 32), ("llm_o", 576, 4096, 4096, "resid", 32),
     ("llm_gu", 576, 22016, 4096, "swiglu", 32), ("llm_down", 576, 4096, 11008, "resid", 32),
-    ("lm_head", 576, 32000, 4096, "store32", 1)]
+    ("lm_head", 576, 32000, 4096, "store32", 1),
+    ("qf_out", 512, 768, 768, "resid", 18), ("qf_xq", 512, 768, 768, "store", 6), ("proj4096", 512, 4096, 768, "store32", 1)]
 
 
 def main():
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--vendor", action="store_true", help="also time torch's library GEMM (hipBLASLt, then rocBLAS) on the same operands: plain "
                     "A @ W^T -> 16-bit, no epilogue — a calibration of what the vendor kernels reach on these shapes, never a product path")
+    ap.add_argument("--audit", action="store_true", help="time every kernel family / forced tile on every shape next to the automatic choice: does the dispatcher pick the fastest?")
     a = ap.parse_args()
     td = hip.torch_dtype(a.dtype)
     only = set(a.only.split(",")) if a.only else None
@@ -60,6 +62,33 @@ def main():
         fl = 2.0 * M * N * K
         total_ms += ms * per_clip; total_fl += fl * per_clip
         print(f"{name:9s} M={M:5d} N={N:6d} K={K:6d} {epi:8s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF   x{per_clip:2d} = {ms * per_clip:6.3f} ms  [{hip.lib().stllm_last_kernel().decode()}]")
+        if a.audit:
+            auto_us, auto_k = ms * 1e3, hip.lib().stllm_last_kernel().decode()
+            rows = []
+            for label, opts in [("128/64 kernels", dict(gemm_p8=0, gemm_w4=0, gemm_sk=0)), ("phased auto", dict(gemm_p8=1, gemm_w4=0)), ("phased 192", dict(gemm_p8=3, gemm_w4=0)),
+                                ("phased 256", dict(gemm_p8=4, gemm_w4=0))] + [(f"w4 {t}", dict(gemm_w4=t)) for t in (32, 42, 34, 24, 33, 43)]:
+                for k_, v_ in opts.items(): hip.set_option(k_, v_)
+                try:
+                    if out is not None: kw["out"] = out
+                    for _ in range(3): hip.gemm(A, W, **kw)
+                    kn = hip.lib().stllm_last_kernel().decode()
+                    s.record()
+                    for _ in range(a.iters): hip.gemm(A, W, **kw)
+                    e.record(); torch.cuda.synchronize()
+                    rows.append((s.elapsed_time(e) / a.iters * 1e3, label, kn))
+                except Exception as ex:   # noqa: BLE001
+                    rows.append((float("inf"), label, f"{type(ex).__name__}"))
+                finally:
+                    for k_ in ("gemm_p8", "gemm_w4", "gemm_sk"): hip.set_option(k_, -1)
+            rows.sort()
+            best = rows[0]
+            flag = "" if best[0] > 0.97 * auto_us else f"   <-- {auto_us - best[0]:.1f} us ({(auto_us - best[0]) * per_clip / 1e3:.3f} ms per clip) faster than the automatic choice"
+            seen = set()
+            for us, label, kn in rows:
+                if kn in seen: continue
+                seen.add(kn)
+                print(f"      {label:15s} {us:8.1f} us  [{kn}]" + (flag if (us, label, kn) == best else ""))
+            assert hip.gemm_workspace_ok()
         if a.vendor:
             Wv = W[:, :K].contiguous()
             for libname in ("hipblaslt", "cublas"):     # torch's name for rocBLAS on ROCm
