@@ -920,11 +920,13 @@ static float old_kernels_estimate_us(const GemmParams& p) {
   return 5.0f + (float)((t128 + 511) / 512) * nk * (t128 >= 512 ? 1.33f : 1.17f);
 }
 
-static bool p8_wanted(const GemmParams& p, int heavy, int* miw) {
+// the phased kernel's ROPE epilogue runs 1.2-1.45x its plain-store estimate (166 vs 116 us at 1088 rows, 942-1039 vs 779 at 9216: dispatch audits of round 4)
+constexpr float kP8RopePenalty = 1.3f;
+static bool p8_wanted(const GemmParams& p, int heavy, int* miw, bool rope = false) {
   const int g_p8_mode = stllm_options().gemm_p8, g_sk_mode = stllm_options().gemm_sk;
   if (g_p8_mode == 0 || p.ws == nullptr) return false;
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
-  const float est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, miw);
+  const float est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, miw) * (rope ? kP8RopePenalty : 1.0f);
   if (g_p8_mode == 3 || g_p8_mode == 4) { *miw = g_p8_mode; return true; }
   if (g_p8_mode == 1) return true;
   if (g_sk_mode >= 1) return false;   // a forced stream-K tile (tests / experiments) wins over the automatic choice
@@ -952,7 +954,11 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   // exchange-free plans only: the one candidate with a K-split that the estimates favour, the Llama qkv GEMM (576 x 12288 x 4096 as
   // 256 whole 192 x 128 tiles + 32 tiles split 8 ways), measured 76.8 vs 81.3 us in the harness but 81.7 us inside bench.py
   // (profiles/r02c_bench_kernel_stats.md) — no gain, so the 128 x 128 kernel keeps it and no model GEMM depends on a w4 exchange
-  if (split != 1 || p.M < 1024) return false;
+  // round 4: with at least one whole round in front of it (and >= 1024 rows) the end-of-launch reduction waits for nobody and its traffic hides behind the rounds — at 2304 rows the
+  // Llama qkv / o / down GEMMs measure 222 / 87 / 189 us on such plans against 298 / 97 / 228 on the phased kernel (profiles/r04_gemm_dispatch_audit_c3_1gpu.log)
+  int plan5[5] = {0, 0, 1, 32, 0};
+  if (split != 1 && stllm_gemm_w4_plan(p.M, p.N, p.K, heavy, *shape, plan5) != STLLM_OK) return false;
+  if ((split != 1 && plan5[0] < 1) || p.M < 1024) return false;
   const float other = p8_est_us < old_kernels_estimate_us(p) ? p8_est_us : old_kernels_estimate_us(p);
   return est < 0.97f * other;
 }
@@ -976,10 +982,11 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
     int miw = 4;
     const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
                     : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;
-    const bool p8_ok = a->epilogue != STLLM_EPI_PATCH && p8_wanted(p, heavy, &miw);
+    const bool rope_epi = a->epilogue == STLLM_EPI_ROPE;
+    const bool p8_ok = a->epilogue != STLLM_EPI_PATCH && p8_wanted(p, heavy, &miw, rope_epi);
     if (a->epilogue != STLLM_EPI_PATCH) {
       int shape = 44, miw2 = 4;
-      const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2);
+      const float p8_est = stllm_gemm_p8_estimate_us(p.M, p.N, p.K, heavy, &miw2) * (rope_epi ? kP8RopePenalty : 1.0f);
       const int thin_bit = (a->epilogue == STLLM_EPI_STORE || a->epilogue == STLLM_EPI_RESID) ? 8 : 0;   // gemm_w4.inc: thin tail rows allowed
       // experiment switch (STLLM_GEMM_W4=3): the automatic rule, plus the Llama prefill qkv GEMM (ROPE epilogue, M < 1024) on the
       // 192 x 128 one-wave tile with its K-split remainder — 78.5 vs 82.9 us in the harness, re-measured in the model every round

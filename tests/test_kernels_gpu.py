@@ -697,6 +697,46 @@ def test_llama_prefill_qkv_runs_on_the_128x256_tile(hip):
     assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
 
 
+@pytest.mark.parametrize("M,N,K,epi,want", [
+    (9216, 12288, 4096, "rope", "gemm_w4_kernel<bf16_t,3,4,ROPE"),      # training forward qkv: 9 whole rounds of 192 x 256 (was the phased kernel: 1040-1060 vs 770-790 us)
+    (1088, 12288, 4096, "rope", "gemm_w4_kernel<bf16_t,"),               # c4's unmasked prefill: a one-wave plan, not the phased kernel's ROPE epilogue (166 vs 121 us)
+    (2304, 4096, 11008, "resid", "gemm_w4_kernel<bf16_t,"),              # c3's batched prefill, down_proj: one whole round + a hidden K-split (228 vs 189-197 us)
+    (32896, 1408, 6144, "resid", "gemm_p8_kernel<bf16_t,4,RESID"),       # ViT fc2 at 128 frames: the 256-row phased tile (582 vs 504 us)
+])
+def test_large_m_dispatch_follows_the_round4_audit(hip, M, N, K, epi, want):
+    """round 4: the cost models were re-calibrated on dispatch audits at 4 k - 66 k rows (tools/gemm_bench.py --audit, profiles/r04_gemm_dispatch_audit_*.log).
+    The choices that moved c3 on one GPU by 5.6 % and the training step's forward qkv by 25 % are pinned here, each checked against the 128 x 128 kernels."""
+    from stllm_amd import pack
+    dtype = "bf16"
+    a, _ = rnd(f"lm.a.{M}.{K}", (M, K), dtype, 0.5)
+    w, _ = rnd(f"lm.w.{N}.{K}", (N, K), dtype, 0.02)
+    kw = dict(dtype=dtype)
+    x = None
+    if epi == "rope":
+        cos, sin = pack.rope_tables(576)
+        kw.update(epilogue=hip.EPI_ROPE, rope=(cos.cuda(), sin.cuda()), rope_seq=576 if M % 576 == 0 else M // 2, rope_cols=8192)
+        if M % 576:
+            cos, sin = pack.rope_tables(M // 2)
+            kw["rope"] = (cos.cuda(), sin.cuda())
+    else:
+        x = T(f"lm.x.{M}.{N}", (M, N), 1.0).cuda()
+        kw.update(epilogue=hip.EPI_RESID)
+    run = lambda: hip.gemm(a, w, **(dict(kw, resid=x.clone()) if x is not None else kw))
+    out = run()
+    name = hip.lib().stllm_last_kernel().decode()
+    assert name.startswith(want), name
+    hip.set_option("gemm_w4", 0); hip.set_option("gemm_p8", 0)
+    try:
+        ref = run()
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemm_kernel<")
+    finally:
+        hip.set_option("gemm_w4", -1); hip.set_option("gemm_p8", -1)
+    d = (out.float() - ref.float()).abs()
+    tol = 1e-3 if x is not None else 2 ** -7     # fp32 residual stream / one bf16 ulp of the 16-bit output
+    assert float((d / ref.float().abs().clamp(min=1.0)).max()) <= tol, float(d.max())
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+
+
 def test_gemm_phased_auto_dispatch(hip):
     """the cost model sends the long-K / few-row-tile prefill shapes to the phased kernel and keeps small problems on
     the 128x128 kernels"""

@@ -29,14 +29,26 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--vendor", action="store_true", help="also time torch's library GEMM (hipBLASLt, then rocBLAS) on the same operands: plain "
                     "A @ W^T -> 16-bit, no epilogue — a calibration of what the vendor kernels reach on these shapes, never a product path")
+    ap.add_argument("--rows", default="", help="vit_rows,llm_rows: the same layer shapes at other row counts (c4: 8224,528 and 8224,1088; c3 on one GPU: 65792,2304; per GPU at N = 8: 8224,580)")
+    ap.add_argument("--train", action="store_true", help="the training step's Llama GEMM shapes instead of the inference ones")
     ap.add_argument("--audit", action="store_true", help="time every kernel family / forced tile on every shape next to the automatic choice: does the dispatcher pick the fastest?")
     a = ap.parse_args()
     td = hip.torch_dtype(a.dtype)
     only = set(a.only.split(",")) if a.only else None
+    shapes = SHAPES
+    if a.train:   # the Llama GEMMs of the training step, 16 clips x 576 tokens = 9216 rows: forward, dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T) with fp32 output
+        R = 9216
+        shapes = [("f_qkv", R, 12288, 4096, "rope", 32), ("f_o", R, 4096, 4096, "resid", 32), ("f_gu", R, 22016, 4096, "store", 32), ("f_down", R, 4096, 11008, "resid", 32),
+                  ("f_lm", R, 32000, 4096, "store32", 1), ("d_qkv", R, 4096, 12288, "store", 32), ("d_o", R, 4096, 4096, "store", 32), ("d_gu", R, 4096, 22016, "store", 32),
+                  ("d_down", R, 11008, 4096, "store", 32), ("d_lm", R, 4096, 32000, "store", 1), ("w_qkv", 12288, 4096, R, "store32", 32), ("w_o", 4096, 4096, R, "store32", 32),
+                  ("w_gu", 22016, 4096, R, "store32", 32), ("w_down", 4096, 11008, R, "store32", 32), ("w_lm", 32000, 4096, R, "store32", 1)]
+    if a.rows:
+        vr, lr = (int(x) for x in a.rows.split(","))
+        shapes = [(n, vr if n.startswith(("vit_", "qf_ckv")) else lr if n.startswith(("llm_", "lm_head")) else M, N, K, e, c) for n, M, N, K, e, c in SHAPES]
     total_ms = 0.0
     total_fl = 0.0
     vendor_ms = {}
-    for name, M, N, K, epi, per_clip in SHAPES:
+    for name, M, N, K, epi, per_clip in shapes:
         if only and name not in only:
             continue
         A = (torch.rand(M, K, device="cuda") * 2 - 1).to(td)
@@ -66,7 +78,7 @@ def main():
             auto_us, auto_k = ms * 1e3, hip.lib().stllm_last_kernel().decode()
             rows = []
             for label, opts in [("128/64 kernels", dict(gemm_p8=0, gemm_w4=0, gemm_sk=0)), ("phased auto", dict(gemm_p8=1, gemm_w4=0)), ("phased 192", dict(gemm_p8=3, gemm_w4=0)),
-                                ("phased 256", dict(gemm_p8=4, gemm_w4=0))] + [(f"w4 {t}", dict(gemm_w4=t)) for t in (32, 42, 34, 24, 33, 43)]:
+                                ("phased 256", dict(gemm_p8=4, gemm_w4=0))] + [(f"w4 {t}", dict(gemm_w4=t)) for t in (32, 42, 34, 24, 33, 43)] + [("automatic, again", dict())]:
                 for k_, v_ in opts.items(): hip.set_option(k_, v_)
                 try:
                     if out is not None: kw["out"] = out
