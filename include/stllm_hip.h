@@ -171,7 +171,7 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *   "norm_fast"  = 1 (default) one row per wave | 2: two rows per wave for >= 2048 short rows (bit-identical results, same speed: an A/B switch)
  *   "gemm_w4_odd" = 1 (default) the 192-column tiles (43 = 256 x 192, 33 = 192 x 192; 16-bit STORE epilogues) take part in the automatic
  *                  choice | 0 the round-2 choice (A/B inside one process: bench.py --ab)
- *   "gemm_w4_wide" = 1 (default) a 16-bit GEMM with the ROPE epilogue whose 128 x 256 tiles make ONE round of 192..256 tiles (the Llama prefill qkv
+ *   "gemm_w4_wide" = 1 (default) a 16-bit GEMM of at most 640 rows whose 128 x 256 tiles make ONE round of 192..256 tiles (the Llama prefill qkv
  *                  GEMM at 385..640 rows: 5 x 48 = 240 tiles at S = 576) runs on the one-wave kernel's 128 x 256 tile (code 24) | 0 on the 128 x 128 kernel */
 int stllm_set_option(const char* key, int value);
 int stllm_gemm(const stllm_gemm_args* args, void* stream);

@@ -996,7 +996,8 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       // Llama prefill qkv (ROPE epilogue, a few hundred rows): the 128 x 256 one-wave tile when its tiles make ONE well-filled round and nothing is
       // exchanged — 576 x 12288 x 4096: 5 x 48 = 240 tiles, 68.8-72 us against 80-82 us on the 128 x 128 kernel (480 tiles = 1.9 rounds) in the
       // harness, profiles/r04_w4_128x256_qkv.md (the vendor library picks the same macro tile for this shape)
-      if (!w4_go && (g_w4_mode == -1 || g_w4_mode == 2 || g_w4_mode == 3) && o_.gemm_w4_wide && a->epilogue == STLLM_EPI_ROPE && !forced_tiles && p.ws != nullptr &&
+      // (any epilogue: the split verify mode's inner GEMM of the same layer is a plain fp32 store at K' = 3 K — 175 vs 230 us on this tile, profiles/r04_gemm_dispatch_audit_x3.log)
+      if (!w4_go && (g_w4_mode == -1 || g_w4_mode == 2 || g_w4_mode == 3) && o_.gemm_w4_wide && p.M <= 640 && !forced_tiles && p.ws != nullptr &&
           p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4 && p.N % 256 == 0) {
         const int t24 = ((p.M + 127) / 128) * (p.N / 256);
         if (t24 >= 192 && t24 <= 256) { shape = 24; w4_go = true; }

@@ -11,7 +11,7 @@ struct StllmOptions {
   int attn_dma;            // STLLM_ATTN_DMA: 1 LDS-DMA attention kernels | 0 register-staged | 2 ...
   int attn_bwd_valu;       // STLLM_ATTN_BWD_VALU: 1 = VALU attention backward also for 16-bit operands
   int gemm_w4_odd;         // STLLM_GEMM_W4_ODD: 1 (default) the 192-column w4 tiles (256 x 192, 192 x 192) take part in the automatic choice | 0 round-2 choice
-  int gemm_w4_wide;        // STLLM_GEMM_W4_WIDE: 1 (default) prefill-sized GEMMs with the ROPE epilogue whose 128 x 256 tiles fill ONE round (192..256 tiles: the Llama qkv GEMM at 385..640 rows) run on the one-wave kernel's 128 x 256 tile | 0 the 128 x 128 kernel (round 1-3)
+  int gemm_w4_wide;        // STLLM_GEMM_W4_WIDE: 1 (default) prefill-sized GEMMs (<= 640 rows) whose 128 x 256 tiles fill ONE round (192..256 tiles: the Llama qkv GEMM at 385..640 rows) run on the one-wave kernel's 128 x 256 tile | 0 the 128 x 128 kernel (round 1-3)
   int attn_f32_mfma;       // STLLM_ATTN_F32_MFMA: 1 (default) fp32 attention on the exact-fp32 matrix-core kernel from 8 query rows on | 0 the vector kernel (round 1-3) everywhere
   int norm_fast;           // STLLM_NORM_FAST: 1 (default) one row per wave | 2 two rows per wave for >= 2048 short rows (bit-identical; measured equal: 22.36 / 22.47 / 22.41 / 22.40 ms per step)
 };

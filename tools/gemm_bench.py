@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--vendor", action="store_true", help="also time torch's library GEMM (hipBLASLt, then rocBLAS) on the same operands: plain "
                     "A @ W^T -> 16-bit, no epilogue — a calibration of what the vendor kernels reach on these shapes, never a product path")
     ap.add_argument("--rows", default="", help="vit_rows,llm_rows: the same layer shapes at other row counts (c4: 8224,528 and 8224,1088; c3 on one GPU: 65792,2304; per GPU at N = 8: 8224,580)")
+    ap.add_argument("--x3", action="store_true", help="the inner bf16 GEMMs of the split verify mode (bf16x3): K' = 3 K, fp32 output (plain store or residual)")
     ap.add_argument("--train", action="store_true", help="the training step's Llama GEMM shapes instead of the inference ones")
     ap.add_argument("--audit", action="store_true", help="time every kernel family / forced tile on every shape next to the automatic choice: does the dispatcher pick the fastest?")
     a = ap.parse_args()
@@ -42,6 +43,8 @@ def main():
                   ("f_lm", R, 32000, 4096, "store32", 1), ("d_qkv", R, 4096, 12288, "store", 32), ("d_o", R, 4096, 4096, "store", 32), ("d_gu", R, 4096, 22016, "store", 32),
                   ("d_down", R, 11008, 4096, "store", 32), ("d_lm", R, 4096, 32000, "store", 1), ("w_qkv", 12288, 4096, R, "store32", 32), ("w_o", 4096, 4096, R, "store32", 32),
                   ("w_gu", 22016, 4096, R, "store32", 32), ("w_down", 4096, 11008, R, "store32", 32), ("w_lm", 32000, 4096, R, "store32", 1)]
+    if a.x3:
+        shapes = [(n, M, N, 3 * K, "resid" if e == "resid" else "store32", c) for n, M, N, K, e, c in shapes]
     if a.rows:
         vr, lr = (int(x) for x in a.rows.split(","))
         shapes = [(n, vr if n.startswith(("vit_", "qf_ckv")) else lr if n.startswith(("llm_", "lm_head")) else M, N, K, e, c) for n, M, N, K, e, c in SHAPES]
