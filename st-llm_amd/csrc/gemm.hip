@@ -958,8 +958,23 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   // Llama qkv / o / down GEMMs measure 222 / 87 / 189 us on such plans against 298 / 97 / 228 on the phased kernel (profiles/r04_gemm_dispatch_audit_c3_1gpu.log)
   int plan5[5] = {0, 0, 1, 32, 0};
   if (split != 1 && stllm_gemm_w4_plan(p.M, p.N, p.K, heavy, *shape, plan5) != STLLM_OK) return false;
-  if ((split != 1 && plan5[0] < 1) || p.M < 1024) return false;
   const float other = p8_est_us < old_kernels_estimate_us(p) ? p8_est_us : old_kernels_estimate_us(p);
+  if (p.M < 1024) {
+    // a few hundred rows (prefill): exchange-free plans of the even tiles only — one partial round of whole tiles is robust inside the model (the 128 x 256 rule above
+    // is the same idea), a K-split at these sizes is not (round 2).  At 296 rows (c5's masked prefill) the qkv GEMM runs 49 us as 192 tiles of 192 x 128 against 68 us on
+    // the phased kernel's ROPE epilogue (profiles/r04_gemm_dispatch_audit_c5.log)
+    if (p.M < 128) return false;
+    static const int kEven[4] = {32, 42, 34, 24};
+    float best = 1.0e30f;
+    for (int i = 0; i < 4; ++i) {
+      int q5[5];
+      if (kEven[i] == 24 && !stllm_options().gemm_w4_wide) continue;   // the A/B switch of the 128 x 256 tile covers this rule too
+      if (stllm_gemm_w4_plan(p.M, p.N, p.K, heavy, kEven[i], q5) != STLLM_OK || q5[2] != 1 || q5[0] != 0) continue;   // ONE partial round (q = 0): the audited case (lm_head as 2.9 rounds of 192 x 128 lost 24 us to the phased kernel)
+      if ((float)q5[4] < best) { best = (float)q5[4]; *shape = kEven[i]; }
+    }
+    return best < 0.97f * other;
+  }
+  if (split != 1 && plan5[0] < 1) return false;
   return est < 0.97f * other;
 }
 

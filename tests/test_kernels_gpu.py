@@ -702,6 +702,7 @@ def test_llama_prefill_qkv_runs_on_the_128x256_tile(hip):
     (1088, 12288, 4096, "rope", "gemm_w4_kernel<bf16_t,"),               # c4's unmasked prefill: a one-wave plan, not the phased kernel's ROPE epilogue (166 vs 121 us)
     (2304, 4096, 11008, "resid", "gemm_w4_kernel<bf16_t,"),              # c3's batched prefill, down_proj: one whole round + a hidden K-split (228 vs 189-197 us)
     (32896, 1408, 6144, "resid", "gemm_p8_kernel<bf16_t,4,RESID"),       # ViT fc2 at 128 frames: the 256-row phased tile (582 vs 504 us)
+    (296, 12288, 4096, "rope", "gemm_w4_kernel<bf16_t,3,2,ROPE"),         # c5's masked prefill: ONE partial round of 192 x 128 tiles, nothing exchanged (68 vs 49 us; c5 34.1 -> 33.0 ms)
 ])
 def test_large_m_dispatch_follows_the_round4_audit(hip, M, N, K, epi, want):
     """round 4: the cost models were re-calibrated on dispatch audits at 4 k - 66 k rows (tools/gemm_bench.py --audit, profiles/r04_gemm_dispatch_audit_*.log).
