@@ -155,8 +155,9 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  * The fused-RMSNorm operand (a_norm_*) exists in the GEMV kernels only: "gemm_gemv" = 0 and forced tile kernels do not apply to it.
  *   "gemm_p8"    = -1 auto (cost model) | 0 off | 1 always (cost model picks the tile height) | 3 / 4 always, 192 / 256-row tile:
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
- *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its exchange-free plan beats the
- *                  other kernels' estimates | 32 / 42 / 34 / 43 / 33 always, 192 x 128 / 256 x 128 / 192 x 256 / 256 x 192 / 192 x 192 tile (44 = 256 x 256 was retired in round 3: unsupported, falls back):
+ *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its plan beats the other kernels' estimates (from 1024 rows on also
+ *                  plans whose K-split hides behind >= 1 whole round; below 1024 rows exchange-free plans of ONE partial round only) | 32 / 42 / 34 / 24 / 43 / 33 always,
+ *                  192 x 128 / 256 x 128 / 192 x 256 / 128 x 256 / 256 x 192 / 192 x 192 tile (44 = 256 x 256 was retired in round 3: unsupported, falls back):
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 16) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernels of the decode regime (st-llm_amd/csrc/gemv.hip):
  *                  the 5 beams of demo.py's beam search, small serving batches (5-row step 6.99 -> 4.34 ms on MI355X)

@@ -5,7 +5,7 @@ struct StllmOptions {
   int gemm_debug;          // STLLM_GEMM_DEBUG: ablation bits
   int gemm_gemv;           // STLLM_GEMM_GEMV: -1 / 2 GEMV kernels up to 16 rows | 1 up to 4 rows | 0 off
   int gemm_p8;             // STLLM_GEMM_P8: -1 auto | 0 off | 1 phased kernel (3 / 4: force 192 / 256 rows)
-  int gemm_w4;             // STLLM_GEMM_W4: -1 auto | 0 off | 1 one-wave-per-SIMD kernel (32 / 34 / 42 / 43 / 33: force the tile) | 3 auto + the Llama prefill qkv GEMM on it (A/B switch)
+  int gemm_w4;             // STLLM_GEMM_W4: -1 auto | 0 off | 1 one-wave-per-SIMD kernel (32 / 34 / 42 / 24 / 43 / 33: force the tile) | 3 auto + the Llama prefill qkv GEMM on it (A/B switch)
   int gemv_mfma;           // STLLM_GEMV_MFMA: -1 matrix-core GEMV from 3 rows | 0 never | n from n rows
   int attn_decode_single;  // 1 one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
   int attn_dma;            // STLLM_ATTN_DMA: 1 LDS-DMA attention kernels | 0 register-staged | 2 ...
