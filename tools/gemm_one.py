@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run ONE GEMM shape a few times (for rocprofv3 --pmc passes).  python tools/gemm_one.py M N K [iters] [store|resid|gelu]"""
+"""Run ONE GEMM shape a few times (for rocprofv3 --pmc passes).  python tools/gemm_one.py M N K [iters] [store|resid|gelu|rope|swiglu]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,12 @@ for _ in range(iters):
         hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_RESID, bias=b, resid=x)
     elif epi == "gelu":
         hip.gemm(A, W, dtype="bf16", bias=b, act=hip.ACT_GELU)
+    elif epi == "swiglu":
+        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_SWIGLU)
+    elif epi == "rope":
+        from stllm_amd import pack
+        cos, sin = pack.rope_tables(M, device="cuda")
+        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=M, rope_cols=(N // 3) * 2 // 128 * 128)
     else:
         hip.gemm(A, W, dtype="bf16")
 torch.cuda.synchronize()

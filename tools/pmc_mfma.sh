@@ -1,6 +1,6 @@
 #!/bin/bash
-# Matrix-pipe busy fraction of the four ViT GEMMs from SQ counters (one counter-only rocprofv3 pass per shape over tools/gemm_one.py):
-#   tools/pmc_mfma.sh   ->  gpurun_out/pmc_mfma/summary.md   (copy to profiles/r03_mfma_busy_pmc.md)
+# Matrix-pipe busy fraction of the four ViT GEMMs and the four Llama prefill GEMMs (every GEMM >= 1 ms per step) from SQ counters (one counter-only rocprofv3 pass per shape over tools/gemm_one.py):
+#   tools/pmc_mfma.sh   ->  gpurun_out/pmc_mfma/summary.md   (copy to profiles/r0N_mfma_busy_pmc.md)
 # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (= 32 x number of 32x32x16 MFMAs); busy fraction = that / (1024 SIMDs x
 # kernel cycles); kernel cycles = GRBM_GUI_ACTIVE of the dispatch / 8 (the counter comes summed over the 8 XCDs: / 8 it is 2.15-2.2 GHz x
 # the kernel-trace duration of the same dispatch for the 55-85 us kernels; MI355X_MICROARCH.md "rocprofv3 PMC slots").
@@ -11,7 +11,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=${TMPDIR:-/tmp}
 cd "$ROOT"
 CTR="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
-for S in "4112 6144 1408 gelu" "4112 4224 1408 store" "4112 1408 1408 resid" "4112 1408 6144 resid"; do
+for S in "4112 6144 1408 gelu" "4112 4224 1408 store" "4112 1408 1408 resid" "4112 1408 6144 resid" "576 12288 4096 rope" "576 4096 4096 resid" "576 22016 4096 swiglu" "576 4096 11008 resid"; do
   set -- $S
   D=$OUT/$1x$2x$3_$4
   timeout 120 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d "$D" -- python tools/gemm_one.py $1 $2 $3 6 $4 > "$D.log" 2>&1 || echo "pass failed: $S (see $D.log)"
