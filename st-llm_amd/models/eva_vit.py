@@ -138,7 +138,9 @@ class VisionTransformer(nn.Module):
         hip.vit_cls_rows(pk["cls"], pk["pos"], out, N)
         return out
 
-    frame_streams = 1   # >1: run groups of frames on concurrent HIP streams (measured slower on MI355X: 31.7 ms vs 33.1 / 38.2 ms at 2 / 4 streams)
+    frame_streams = 1   # >1: run groups of frames on concurrent HIP streams (measured slower on MI355X: 31.7 ms vs 33.1 / 38.2 ms at 2 / 4 streams in round 1;
+                        # 23.12 vs 25.75-25.92 ms at 2 streams on the round-4 kernels, `bench.py --vit-streams 2`: one workgroup per CU owns the whole LDS, so the
+                        # second stream's kernels only get the CUs the first leaves idle and every weight matrix is streamed twice)
 
     def _features_group(self, x, pk, dt, out):
         n = x.shape[0]
