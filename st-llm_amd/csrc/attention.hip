@@ -1131,6 +1131,17 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
       // 6 x 2: 27.1 / 48.6, 4 x 2: 21.5 / 53.4, 3 x 4: 22.7 / 62.1 (register-staged kernel: 28.0 / 75.3) — the fewest key-split
       // waves that still give >= 128 workgroups
       const int q_tiles = (p.Sq + 31) / 32, bh = p.B * p.H;
+      if (g_attn_dma >= 10) {   // experiments (tools/attn_bench.py --audit): attn_dma = 10 x (query tiles per workgroup) + (waves per query tile), at most 12 waves
+        const int nwf = g_attn_dma / 10, ks = g_attn_dma % 10;
+        if (nwf >= 1 && nwf * ks <= 12) {
+          if (ks == 1) return launch_dma<T, 1>(p, stream, nwf);
+          if (ks == 2) return launch_dma<T, 2>(p, stream, nwf);
+          if (ks == 4) return launch_dma<T, 4>(p, stream, nwf);
+        }
+      }
+      // round 4 (tools/attn_bench.py --audit, profiles/r04_attn_dispatch_audit.log): one sequence of <= 640 positions (32 heads) runs best as 2 query tiles x 4 key-split
+      // waves per workgroup — 10.8 / 13.0 / 14.9 / 19.0 / 19.1 us at S = 178 / 296 / 400 / 528 / 576 against 14.2 / 16.2 / 17.0 / 20.5 / 20.6 on the rules below
+      if (bh <= 32 && q_tiles <= 20) return launch_dma<T, 4>(p, stream, 2);
       if (bh * ((q_tiles + 11) / 12) >= 128) return launch_dma<T, 1>(p, stream, 12);
       if (bh * ((q_tiles + 3) / 4) >= 128) return launch_dma<T, 2>(p, stream, 4);
       return launch_dma<T, 4>(p, stream, 3);
