@@ -164,7 +164,8 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *   "gemv_mfma"  = -1 matrix-core GEMV (v_mfma_f32_16x16x32) from M = 3, the VALU kernel (v_dot2c) below | 0 never (M > 8 then runs on the
  *                  tile kernels) | 1 from M = 1
  *   "attn_dma"   = 1 (default) attention at head_dim 128 (Llama prefill) and 88 (ViT) staged by LDS-DMA, V through the transposing LDS read |
- *                  0 register-staged kernels
+ *                  0 register-staged kernels | 10 nw + ks (nw x ks <= 12, ks in 1 / 2 / 4): force the head_dim-128 kernel's work split — nw query tiles per
+ *                  workgroup x ks key-split waves per tile (tools/attn_bench.py --audit)
  *   "attn_decode_single" = 1 (default) one-workgroup-per-head decode attention for Skv <= 1536 | 0 always the split-KV pair
  *   "gemm_sk"    = -1 auto | 0 off | 1 (128x128) | 2 (128x256) | 3 (256x256): stream-K tile of the older kernels
  *   "gemm_debug" = ablation bits of the 128x128 kernels; bit 16 = in-kernel timeline of the phased kernel (tools/gemm_harness.cpp)
