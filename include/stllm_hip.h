@@ -232,6 +232,40 @@ int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, in
 /* the decoder-layer loop of the PREFILL (st_llm.py:56-92 -> HF LlamaModel.forward, use_cache False or filling a fresh cache) */
 int stllm_llama_layers(const stllm_llama_layers_args* args, const stllm_llama_layer_weights* layers, int n_layers, void* stream);
 
+/* BertSelfOutput / BertOutput (Qformer.py:281-289, 384-400): LayerNorm(dense(x) + input) */
+typedef struct {
+  const void* w; int64_t ldw; const float* b;  /* dense [hidden, in], bias f32 [hidden] */
+  const float* g; const float* beta; float eps;/* LayerNorm weight / bias f32 [hidden] */
+} stllm_bert_output_weights;
+/* one Q-Former BertLayer (Qformer.py:367-484): fused self-attention [q | k | v] rows, attention.output, on the layers with cross-attention
+ * (has_cross: layer_num % cross_attention_freq == 0) crossattention.self.query + crossattention.output — the cross K / V projections of ALL
+ * layers live in ONE weight (stllm_qformer_layers_args.ckv_w; ckv_index = this layer's [k | v] column block in its output) —, the query
+ * rows' FFN (intermediate_query / output_query) and, with text rows, the text FFN (intermediate / output; ft_w1 NULL otherwise) */
+typedef struct {
+  const void* wqkv; int64_t ld_qkv; const float* bqkv;
+  stllm_bert_output_weights attn_out;
+  int has_cross; int ckv_index;
+  const void* cq_w; int64_t ld_cq; const float* cq_b;
+  stllm_bert_output_weights cross_out;
+  const void* fq_w1; int64_t ld_fq1; const float* fq_b1; stllm_bert_output_weights fq_out;
+  const void* ft_w1; int64_t ld_ft1; const float* ft_b1; stllm_bert_output_weights ft_out;
+} stllm_qformer_layer_weights;
+typedef struct {
+  int dtype; int n_seq; int n_query; int n_text; int n_heads; int hidden; int inter; int enc_len; int enc_dim; int n_cross;
+  float* hq32; void* hq16;                     /* query rows [n_seq * n_query, hidden]: fp32 post-LN stream + its compute-dtype copy, both updated in place */
+  float* ht32; void* ht16;                     /* text rows [n_seq * n_text, hidden] likewise (NULL when n_text == 0) */
+  const void* enc16; int64_t ld_enc;           /* ln_vision'd image tokens, compute dtype [n_seq * enc_len, enc_dim] */
+  const void* ckv_w; int64_t ld_ckv; const float* ckv_b;   /* [n_cross * 2 hidden, enc_dim]: (key | value) rows of the cross layers in layer order */
+  const int32_t* kv_len;                       /* int32 [n_seq] = n_query + valid text tokens (right-padded text), or NULL */
+  void* scratch; int64_t scratch_bytes;        /* >= stllm_qformer_layers_scratch_bytes(...), 256-byte aligned, no initialisation */
+  void* workspace; int64_t workspace_bytes;    /* the stllm_gemm workspace of the launch stream */
+} stllm_qformer_layers_args;
+int64_t stllm_qformer_layers_scratch_bytes(int dtype, int n_seq, int n_query, int n_text, int hidden, int inter, int enc_len, int enc_dim, int n_cross);
+/* BertEncoder.forward's layer loop (Qformer.py:495-589; BertLayer.forward :402-484) on the embedded rows: self-attention over [queries | text],
+ * cross-attention of the query rows against the image tokens on the has_cross layers, the two FFNs.  STLLM_BF16X3: fp32 activations, every
+ * Linear split inside its GEMM (no pre-split images: the rows are too few for the split passes to matter). */
+int stllm_qformer_layers(const stllm_qformer_layers_args* args, const stllm_qformer_layer_weights* layers, int n_layers, void* stream);
+
 /*
  * Decode attention: ONE query row per (batch, head) against Skv cached keys (the one-token step of generate(), SURVEY §8f
  * rank 1; HF LlamaAttention with past_key_values, spec modeling_llama_mem.py:172-248).  HBM-bound: the keys are split over

@@ -23,7 +23,7 @@ void stllm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* stllm_last_error(void) { return g_err; }
-extern "C" int stllm_abi_version(void) { return 5; }   // 5 (round 4): STLLM_BF16X3 + stllm_gemm_args.split_ws / stllm_split3_rows / stllm_gemm_split_ws_bytes; the fold_* fields, stllm_row_stats and stllm_gemm_fold_supported of ABI 4 are gone.  2: stllm_gemm_args gained the trailing a_norm_* fields (round 2); 3: whole-stack entry points, stllm_gemm_profile*, per-thread options; 4: stllm_gemm_args fold_* (LayerNorm folded into the GEMMs), stllm_row_stats (round 3)
+extern "C" int stllm_abi_version(void) { return 6; }   // 6 (round 5): stllm_qformer_layers (the third whole-stack family).  5 (round 4): STLLM_BF16X3 + stllm_gemm_args.split_ws / stllm_split3_rows / stllm_gemm_split_ws_bytes; the fold_* fields, stllm_row_stats and stllm_gemm_fold_supported of ABI 4 are gone.  2: stllm_gemm_args gained the trailing a_norm_* fields (round 2); 3: whole-stack entry points, stllm_gemm_profile*, per-thread options; 4: stllm_gemm_args fold_* (LayerNorm folded into the GEMMs), stllm_row_stats (round 3)
 
 // ---- per-thread dispatch options (common.h) ----
 static int env_int(const char* name, int dflt) {

@@ -218,3 +218,132 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
   }
   return STLLM_OK;
 }
+
+namespace {
+
+inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+// split workspace of the Q-Former stack in the split mode: the largest split A operand among its GEMMs (none is pre-split)
+int64_t qformer_split_ws(int64_t nq, int64_t nt, int64_t nenc, int C, int inter, int enc_dim, int n_cross) {
+  const int64_t rows = max64(nq, nt);
+  int64_t w = max64(stllm_gemm_split_ws_bytes((int)rows, 3 * C, C, STLLM_EPI_STORE, 0), stllm_gemm_split_ws_bytes((int)rows, C, C, STLLM_EPI_RESID, 0));
+  w = max64(w, stllm_gemm_split_ws_bytes((int)rows, inter, C, STLLM_EPI_STORE, 0));
+  w = max64(w, stllm_gemm_split_ws_bytes((int)rows, C, inter, STLLM_EPI_RESID, 0));
+  if (n_cross > 0) w = max64(w, stllm_gemm_split_ws_bytes((int)nenc, n_cross * 2 * C, enc_dim, STLLM_EPI_STORE, 0));
+  return w;
+}
+
+}  // namespace
+
+extern "C" int64_t stllm_qformer_layers_scratch_bytes(int dtype, int n_seq, int n_query, int n_text, int hidden, int inter, int enc_len, int enc_dim, int n_cross) {
+  if (n_seq <= 0 || n_query <= 0 || n_text < 0 || hidden <= 0 || inter <= 0 || enc_len < 0 || enc_dim < 0 || n_cross < 0 || !dtype_ok(dtype)) return -1;
+  const int64_t e = esize(dtype), S = n_query + n_text, nq = (int64_t)n_seq * n_query, nt = (int64_t)n_seq * n_text, rows = max64(nq, nt);
+  int64_t need = up256((int64_t)n_seq * S * 3 * hidden * e) + up256((int64_t)n_seq * S * hidden * e) + up256(rows * hidden * 4) + up256(rows * inter * e);
+  if (n_cross > 0) need += 2 * up256(nq * hidden * e) + up256((int64_t)n_seq * enc_len * n_cross * 2 * hidden * e);
+  if (dtype == STLLM_BF16X3) need += up256(qformer_split_ws(nq, nt, (int64_t)n_seq * enc_len, hidden, inter, enc_dim, n_cross));
+  return need;
+}
+
+extern "C" int stllm_qformer_layers(const stllm_qformer_layers_args* a, const stllm_qformer_layer_weights* layers, int n_layers, void* stream) {
+  if (!a || (!layers && n_layers > 0) || n_layers < 0) { stllm_set_error("stllm_qformer_layers: null arguments"); return STLLM_ERR_BAD_SHAPE; }
+  if (!dtype_ok(a->dtype)) { stllm_set_error("stllm_qformer_layers: bad dtype %d", a->dtype); return STLLM_ERR_BAD_DTYPE; }
+  if (a->n_seq <= 0 || a->n_query <= 0 || a->n_text < 0 || a->n_heads <= 0 || a->hidden <= 0 || a->inter <= 0 || a->hidden % a->n_heads != 0 || a->n_cross < 0 ||
+      !a->hq32 || !a->hq16 || !a->scratch || (a->n_text > 0 && (!a->ht32 || !a->ht16)) ||
+      (a->n_cross > 0 && (!a->enc16 || !a->ckv_w || a->enc_len <= 0 || a->enc_dim <= 0 || a->ld_enc < a->enc_dim))) {
+    stllm_set_error("stllm_qformer_layers: bad dims (seqs %d, queries %d, text %d, heads %d, hidden %d, inter %d, image tokens %d x %d, cross layers %d) / null buffers",
+                    a->n_seq, a->n_query, a->n_text, a->n_heads, a->hidden, a->inter, a->enc_len, a->enc_dim, a->n_cross);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  int cross_seen = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const stllm_qformer_layer_weights& w = layers[l];
+    const bool cross_bad = w.has_cross && (!w.cq_w || !w.cross_out.w || w.ckv_index < 0 || w.ckv_index >= a->n_cross);
+    if (!w.wqkv || !w.attn_out.w || !w.fq_w1 || !w.fq_out.w || cross_bad || (a->n_text > 0 && (!w.ft_w1 || !w.ft_out.w))) {
+      stllm_set_error("stllm_qformer_layers: layer %d lacks a weight the call needs (cross %d of %d, text rows %d)", l, w.has_cross ? w.ckv_index : -1, a->n_cross, a->n_text);
+      return STLLM_ERR_BAD_SHAPE;
+    }
+    cross_seen += w.has_cross ? 1 : 0;
+  }
+  (void)cross_seen;
+  const int64_t need = stllm_qformer_layers_scratch_bytes(a->dtype, a->n_seq, a->n_query, a->n_text, a->hidden, a->inter, a->enc_len, a->enc_dim, a->n_cross);
+  if (need < 0 || a->scratch_bytes < need) {
+    stllm_set_error("stllm_qformer_layers: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const int n = a->n_seq, Q = a->n_query, Lt = a->n_text, S = Q + Lt, C = a->hidden, H = a->n_heads, hd = C / H, P = a->enc_len;
+  const int e = esize(a->dtype), adt = act_dtype(a->dtype);
+  const int64_t nq = (int64_t)n * Q, nt = (int64_t)n * Lt, rows = max64(nq, nt);
+  const int64_t ld_ckv_out = (int64_t)a->n_cross * 2 * C;
+  Carver c(a->scratch, a->scratch_bytes);
+  char* qkv = reinterpret_cast<char*>(c.take((int64_t)n * S * 3 * C * e));
+  char* ctx = reinterpret_cast<char*>(c.take((int64_t)n * S * C * e));
+  float* tmp = reinterpret_cast<float*>(c.take(rows * C * 4));
+  char* g1 = reinterpret_cast<char*>(c.take(rows * a->inter * e));
+  char *cq = nullptr, *cctx = nullptr, *ckv = nullptr;
+  if (a->n_cross > 0) {
+    cq = reinterpret_cast<char*>(c.take(nq * C * e));
+    cctx = reinterpret_cast<char*>(c.take(nq * C * e));
+    ckv = reinterpret_cast<char*>(c.take((int64_t)n * P * ld_ckv_out * e));
+  }
+  void* sws = nullptr;
+  int64_t sws_bytes = 0;
+  if (a->dtype == STLLM_BF16X3) {
+    sws_bytes = qformer_split_ws(nq, nt, (int64_t)n * P, C, a->inter, a->enc_dim, a->n_cross);
+    sws = c.take(sws_bytes);
+  }
+  const float scale = (float)(1.0 / __builtin_sqrt((double)hd));
+  // LayerNorm(dense(x) + input) of `m` rows: x = A (2-level rows when a_rpb > 0), input / result = the fp32 stream h32 with its compute-dtype copy h16
+  auto post_ln = [&](const void* A, int64_t lda, int a_rpb, int64_t a_bs, int K, const stllm_bert_output_weights& o, float* h32, void* h16, int64_t m) -> int {
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+    g.epilogue = STLLM_EPI_RESID; g.A = A; g.lda = lda; g.a_rows_per_batch = a_rpb; g.a_batch_stride = a_bs; g.W = o.w; g.ldw = o.ldw; g.bias = o.b;
+    g.resid = h32; g.ldr = C; g.out = tmp; g.ldo = C; g.M = (int)m; g.N = C; g.K = K;
+    STACK_TRY(stllm_gemm(&g, stream));
+    return stllm_layernorm(adt, tmp, C, o.g, o.beta, o.eps, h16, C, h32, C, (int)m, C, stream);
+  };
+  bool ckv_done = false;
+  for (int l = 0; l < n_layers; ++l) {
+    const stllm_qformer_layer_weights& w = layers[l];
+    // ---- self-attention over [queries | text] (Qformer.py:417-424): both row groups write their rows of ONE fused [n, S, 3 C] buffer ----
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+    g.epilogue = STLLM_EPI_STORE; g.A = a->hq16; g.lda = C; g.W = w.wqkv; g.ldw = w.ld_qkv; g.bias = w.bqkv; g.out = qkv; g.ldo = 3 * C; g.M = (int)nq; g.N = 3 * C; g.K = C;
+    if (Lt) { g.o_rows_per_batch = Q; g.o_batch_stride = (int64_t)S * 3 * C; }
+    STACK_TRY(stllm_gemm(&g, stream));
+    if (Lt) {
+      g.A = a->ht16; g.out = qkv + (int64_t)Q * 3 * C * e; g.M = (int)nt; g.o_rows_per_batch = Lt;
+      STACK_TRY(stllm_gemm(&g, stream));
+    }
+    const int64_t rs = 3 * C, bs = (int64_t)S * rs;
+    STACK_TRY(stllm_attention(adt, qkv, bs, rs, qkv + (int64_t)C * e, bs, rs, qkv + (int64_t)2 * C * e, bs, rs, ctx, (int64_t)S * C, C, n, H, S, S, hd, scale, 0, a->kv_len, stream));
+    STACK_TRY(post_ln(ctx, C, Lt ? Q : 0, Lt ? (int64_t)S * C : 0, C, w.attn_out, a->hq32, a->hq16, nq));
+    if (Lt) STACK_TRY(post_ln(ctx + (int64_t)Q * C * e, C, Lt, (int64_t)S * C, C, w.attn_out, a->ht32, a->ht16, nt));
+    // ---- cross-attention, query rows only (Qformer.py:430-444) ----
+    if (w.has_cross) {
+      g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+      g.epilogue = STLLM_EPI_STORE; g.A = a->hq16; g.lda = C; g.W = w.cq_w; g.ldw = w.ld_cq; g.bias = w.cq_b; g.out = cq; g.ldo = C; g.M = (int)nq; g.N = C; g.K = C;
+      STACK_TRY(stllm_gemm(&g, stream));
+      if (!ckv_done) {   // the K / V projections of every cross layer in one GEMM over the image tokens
+        g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+        g.epilogue = STLLM_EPI_STORE; g.A = a->enc16; g.lda = a->ld_enc; g.W = a->ckv_w; g.ldw = a->ld_ckv; g.bias = a->ckv_b; g.out = ckv; g.ldo = ld_ckv_out;
+        g.M = n * P; g.N = (int)ld_ckv_out; g.K = a->enc_dim;
+        STACK_TRY(stllm_gemm(&g, stream));
+        ckv_done = true;
+      }
+      const char* kk = ckv + (int64_t)w.ckv_index * 2 * C * e;
+      STACK_TRY(stllm_attention(adt, cq, (int64_t)Q * C, C, kk, (int64_t)P * ld_ckv_out, ld_ckv_out, kk + (int64_t)C * e, (int64_t)P * ld_ckv_out, ld_ckv_out, cctx, (int64_t)Q * C, C,
+                                n, H, Q, P, hd, scale, 0, nullptr, stream));
+      STACK_TRY(post_ln(cctx, C, 0, 0, C, w.cross_out, a->hq32, a->hq16, nq));
+    }
+    // ---- FFN: query rows through *_query, text rows through the text weights (Qformer.py:449-462) ----
+    g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
+    g.epilogue = STLLM_EPI_STORE; g.act = STLLM_ACT_GELU; g.A = a->hq16; g.lda = C; g.W = w.fq_w1; g.ldw = w.ld_fq1; g.bias = w.fq_b1; g.out = g1; g.ldo = a->inter;
+    g.M = (int)nq; g.N = a->inter; g.K = C;
+    STACK_TRY(stllm_gemm(&g, stream));
+    STACK_TRY(post_ln(g1, a->inter, 0, 0, a->inter, w.fq_out, a->hq32, a->hq16, nq));
+    if (Lt) {
+      g.A = a->ht16; g.W = w.ft_w1; g.ldw = w.ld_ft1; g.bias = w.ft_b1; g.M = (int)nt;
+      STACK_TRY(stllm_gemm(&g, stream));
+      STACK_TRY(post_ln(g1, a->inter, 0, 0, a->inter, w.ft_out, a->ht32, a->ht16, nt));
+    }
+  }
+  return STLLM_OK;
+}

@@ -25,7 +25,7 @@ EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
            "stllm_attention_decode", "stllm_gemm_profile", "stllm_gemm_profile_count", "stllm_gemm_profile_read",
            "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers",
-           "stllm_split3_rows", "stllm_gemm_split_ws_bytes"]
+           "stllm_qformer_layers_scratch_bytes", "stllm_qformer_layers", "stllm_split3_rows", "stllm_gemm_split_ws_bytes"]
 
 
 def torch_dtype(d):
@@ -78,6 +78,26 @@ class LlamaLayersArgs(ctypes.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64)]
 
 
+class BertOutputWeights(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("ldw", c_int64), ("b", c_void_p), ("g", c_void_p), ("beta", c_void_p), ("eps", c_float)]
+
+
+class QformerLayerWeights(ctypes.Structure):
+    _fields_ = [("wqkv", c_void_p), ("ld_qkv", c_int64), ("bqkv", c_void_p), ("attn_out", BertOutputWeights),
+                ("has_cross", c_int), ("ckv_index", c_int), ("cq_w", c_void_p), ("ld_cq", c_int64), ("cq_b", c_void_p),
+                ("cross_out", BertOutputWeights),
+                ("fq_w1", c_void_p), ("ld_fq1", c_int64), ("fq_b1", c_void_p), ("fq_out", BertOutputWeights),
+                ("ft_w1", c_void_p), ("ld_ft1", c_int64), ("ft_b1", c_void_p), ("ft_out", BertOutputWeights)]
+
+
+class QformerLayersArgs(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("n_seq", c_int), ("n_query", c_int), ("n_text", c_int), ("n_heads", c_int), ("hidden", c_int), ("inter", c_int),
+                ("enc_len", c_int), ("enc_dim", c_int), ("n_cross", c_int),
+                ("hq32", c_void_p), ("hq16", c_void_p), ("ht32", c_void_p), ("ht16", c_void_p),
+                ("enc16", c_void_p), ("ld_enc", c_int64), ("ckv_w", c_void_p), ("ld_ckv", c_int64), ("ckv_b", c_void_p),
+                ("kv_len", c_void_p), ("scratch", c_void_p), ("scratch_bytes", c_int64), ("workspace", c_void_p), ("workspace_bytes", c_int64)]
+
+
 LIB_PATH = os.environ.get("STLLM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libstllm_hip.so")   # STLLM_LIB: the trace build (tools only)
 _lib = None
 
@@ -127,6 +147,8 @@ def _bind(L, strict=True):
     B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
     B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
     B("stllm_llama_layers", [ctypes.POINTER(LlamaLayersArgs), ctypes.POINTER(LlamaLayerWeights), c_int, c_void_p])
+    B("stllm_qformer_layers_scratch_bytes", [c_int] * 9, c_int64)
+    B("stllm_qformer_layers", [ctypes.POINTER(QformerLayersArgs), ctypes.POINTER(QformerLayerWeights), c_int, c_void_p])
     B("stllm_gemm_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
     B("stllm_gemm_w4_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
     return L
@@ -580,6 +602,66 @@ def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=Non
                         _p(kv_len), cache.max_len if cache is not None else 0, scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
     _check(L.stllm_llama_layers(ctypes.byref(a), carr, len(layers), _stream()), "stllm_llama_layers")
     return x
+
+
+def _bert_out(dst, o):
+    dst.w, dst.ldw, dst.b = o["w"].data_ptr(), o["w"].stride(0), o["b"].data_ptr()
+    dst.g, dst.beta, dst.eps = o["g"].data_ptr(), o["beta"].data_ptr(), float(o["eps"])
+
+
+def qformer_layer_array(layers):
+    """list of BertLayer.pack() dicts -> ctypes array of stllm_qformer_layer_weights (the caller keeps `layers` alive next to it)"""
+    arr = (QformerLayerWeights * len(layers))()
+    for i, pk in enumerate(layers):
+        w = arr[i]
+        w.wqkv, w.ld_qkv, w.bqkv = pk["wqkv"].data_ptr(), pk["wqkv"].stride(0), pk["bqkv"].data_ptr()
+        _bert_out(w.attn_out, pk["attn_out"])
+        w.has_cross = int("cq_w" in pk)
+        if w.has_cross:
+            w.ckv_index = pk["ckv_all"][2]
+            w.cq_w, w.ld_cq, w.cq_b = pk["cq_w"].data_ptr(), pk["cq_w"].stride(0), pk["cq_b"].data_ptr()
+            _bert_out(w.cross_out, pk["cross_out"])
+        f = pk["ffn_q"]
+        w.fq_w1, w.ld_fq1, w.fq_b1 = f["w1"].data_ptr(), f["w1"].stride(0), f["b1"].data_ptr()
+        _bert_out(w.fq_out, f["out"])
+        f = pk.get("ffn_t")
+        if f is not None:
+            w.ft_w1, w.ld_ft1, w.ft_b1 = f["w1"].data_ptr(), f["w1"].stride(0), f["b1"].data_ptr()
+            _bert_out(w.ft_out, f["out"])
+    return arr
+
+
+def qformer_layers(hq32, hq16, ht32, ht16, enc16, layers, carr, *, n_seq, n_query, n_text, n_heads, dtype, kv_len=None):
+    """All Q-Former layers of `layers` (BertLayer.pack() dicts; carr = qformer_layer_array(layers)) on the embedded query rows hq32 / hq16
+    [n_seq * n_query, C] and text rows ht32 / ht16 [n_seq * n_text, C] (None without text), in place — ONE C call (stllm_qformer_layers).
+    enc16: the ln_vision'd image tokens, compute dtype [n_seq * P, 1408]."""
+    _req(hq32, torch.float32, "hq32")
+    td = torch_dtype(dtype)
+    C, inter = hq32.shape[1], layers[0]["ffn_q"]["w1"].shape[0]
+    cross = [pk for pk in layers if "cq_w" in pk]
+    w_all = b_all = None
+    n_cross = P = enc_dim = 0
+    if cross:
+        w_all, b_all, _, n_cross = cross[0]["ckv_all"]
+        P, enc_dim = enc16.shape[0] // n_seq, enc16.shape[1]
+    L = lib()
+    code = stack_dtype_code(td, layers[0]["ffn_q"]["w1"])
+    _req(hq16, td, "hq16"); _req(enc16, td, "enc16") if cross else None
+    if n_text:
+        _req(ht32, torch.float32, "ht32"); _req(ht16, td, "ht16")
+    if kv_len is not None:
+        _req(kv_len, torch.int32, "kv_len")
+    need = int(L.stllm_qformer_layers_scratch_bytes(code, n_seq, n_query, n_text, C, inter, P, enc_dim, n_cross))
+    if need < 0:
+        raise RuntimeError("stllm_qformer_layers_scratch_bytes: bad shape")
+    scratch = torch.empty(need, dtype=torch.uint8, device=hq32.device)
+    ws = gemm_workspace(hq32.device)
+    a = QformerLayersArgs(code, n_seq, n_query, n_text, n_heads, C, inter, P, enc_dim, n_cross, hq32.data_ptr(), hq16.data_ptr(),
+                          _p(ht32) if n_text else None, _p(ht16) if n_text else None, _p(enc16) if cross else None,
+                          enc16.stride(0) if cross else 0, _p(w_all), w_all.stride(0) if cross else 0, _p(b_all), _p(kv_len),
+                          scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
+    _check(L.stllm_qformer_layers(ctypes.byref(a), carr, len(layers), _stream()), "stllm_qformer_layers")
+    return hq32, hq16, ht32
 
 
 def _norm_dtype(dtype, D):

@@ -133,6 +133,7 @@ class BertModel(nn.Module):
         self.embeddings = BertEmbeddings(config, device)
         self.encoder = BertEncoder(config, device)
         self._packed = {}
+        self._carr = {}   # C-side table of the packed layers: rebuilt when they are re-packed
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
@@ -150,13 +151,16 @@ class BertModel(nn.Module):
                     pk["ckv_all"] = (w_all, b_all, j, len(cross))
             hit = (fp, layers)
             self._packed = {dt: hit}
+            self._carr = {}
         return hit[1]
 
     def repack(self):
         self._packed = {}
+        self._carr = {}
 
     def _load_from_state_dict(self, *a, **k):
         self._packed = {}
+        self._carr = {}
         return super()._load_from_state_dict(*a, **k)
 
     # ------------------------------------------------------------------------------------------
@@ -187,6 +191,21 @@ class BertModel(nn.Module):
             kv_len = hip.h2d((Q + text_mask.long().sum(dim=1)).to(torch.int32), dev)
             m = text_mask.long()
             assert bool((m[:, 1:] <= m[:, :-1]).all()), "Q-Former text mask must be right-padded (padding='longest')"
+        from . import llama as _llama
+        if _llama.STACK_ENTRY:   # Qformer.py:495-589: the whole layer loop is ONE call into the C ABI (stllm_qformer_layers; == encode_layers_per_op, bit for bit)
+            if self._carr.get("layers") is not layers:
+                self._carr = {"layers": layers, "carr": hip.qformer_layer_array(layers)}
+            return hip.qformer_layers(hq32, hq16, ht32, ht16, enc16, layers, self._carr["carr"], n_seq=n, n_query=Q, n_text=Lt, n_heads=H,
+                                      dtype=dt, kv_len=kv_len)
+        return self.encode_layers_per_op(layers, hq32, hq16, ht32, ht16, enc16, n, Q, Lt, kv_len, dt)
+
+    def encode_layers_per_op(self, layers, hq32, hq16, ht32, ht16, enc16, n, Q, Lt, kv_len, dt):
+        """The BertLayer loop as one C-ABI call per op — what stllm_qformer_layers issues from C.  Kept as the reference the stack entry
+        point is tested against (-m gpu: bit-identical) and as the body the test-only CPU contract backend runs."""
+        cfg = self.config
+        C, H = cfg.hidden_size, cfg.num_attention_heads
+        dev = hq32.device
+        P = enc16.shape[0] // n
         S = Q + Lt
         qkv = torch.empty((n * S, 3 * C), device=dev, dtype=dt)
         rows_q = dict(M=n * Q, o_rows=(Q, S * 3 * C)) if Lt else {}

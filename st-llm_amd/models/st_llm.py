@@ -254,11 +254,16 @@ class STLLMModel(Blip2Base):
         return get_residual_index(sample_segments, total_segments)
 
     # ------------------------------------------------------------------------------------------
+    def _upload_rows(self, rows, device):
+        """rows: list (B) of lists of gather indices (>=0: row of the visual-token block; <0: -(token id)-1) — all the same length.
+        Host -> device through the pinned ring (asynchronous): forward() does this BEFORE the encode is enqueued, so the table is
+        resident long before the gather that reads it and the host never makes the GPU wait between the projector and the prefill."""
+        return hip.h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1), device), len(rows), len(rows[0])
+
     def _gather_tokens(self, vis_flat, rows):
-        """rows: list (B) of lists of gather indices (>=0: row of vis_flat; <0: -(token id)-1) — all the same
-        length.  One kernel assembles inputs_embeds [B,S,D] from visual tokens + embedding-table rows."""
-        B, S = len(rows), len(rows[0])
-        idx = hip.h2d(torch.tensor(rows, dtype=torch.int32).reshape(-1), vis_flat.device)
+        """One kernel assembles inputs_embeds [B,S,D] from visual tokens + embedding-table rows (rows: index lists, or the
+        (idx, B, S) triple _upload_rows returned for them)."""
+        idx, B, S = rows if isinstance(rows, tuple) else self._upload_rows(rows, vis_flat.device)
         out = hip.gather_rows(vis_flat, idx, src_b=self.embed_tokens.weight)
         if self._tape is not None:
             self._tape.setdefault("gather_idx", []).append(idx)
@@ -329,59 +334,86 @@ class STLLMModel(Blip2Base):
             if "mask" in samples and samples["mask"] is not None:
                 samples["mask"] = torch.as_tensor(samples["mask"])[own]
             clip_sharded = True
-        img_embeds, atts_img, use_image = self.encode_img(image, qtext)
-        if not use_image:
-            img_embeds = self.pool_video(img_embeds)
-        elif img_embeds.dim() == 3:
-            img_embeds = img_embeds.unsqueeze(1)
+        # ---- host-side plan FIRST: everything below up to encode_img depends on shapes and token ids only, not on a single device result.
+        # Built (and its index tables enqueued for upload) before the encode, it costs no GPU time; built after it — rounds 1-4 — the GPU
+        # sat idle for the tokenizers and _assemble between the projector and the first RMSNorm (profiles/r04_bench_gaps_final.md: 0.65 ms).
+        dev = image.device
+        T = image.shape[1]
+        use_image = bool(T == 1 or image.dim() == 4)        # encode_img's rule (st_llm.py:326-328)
+        Lq = self.query_tokens.shape[1]
+        if use_image:
+            L = Lq
+        elif self.video_input == "all":
+            L = T * Lq
+        elif self.video_input == "residual":
+            L = self.residual_size * Lq
+        else:                                                # "mean"; None leaves [B,T,32,D] — which the reference's assembly cannot take either
+            L = Lq
+        B = image.shape[0]
         answers_txt = list(samples["answer"])
+        own = None
         if self.frame_parallel is not None and not use_image and not clip_sharded:
             # clip-parallel prefill: this rank continues with the clips it owns (clip c -> rank c % world)
             from .. import parallel
             rank, world, _ = self.frame_parallel
             own = parallel.clips_of_rank(image.shape[0], rank, world)
             self.owned_clips = own
+            if own:
+                if instruction is not None and not isinstance(instruction, str):
+                    instruction = [instruction[c] for c in own]
+                answers_txt = [answers_txt[c] for c in own]
+                if "mask" in samples and samples["mask"] is not None:
+                    samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
+                B = len(own)
+        plan = None
+        if own is None or own:
+            kept = [list(range(L)) for _ in range(B)]
+            mask = None
+            if not use_image and self.use_mask:
+                self.img_len = L
+                if "mask" in samples and samples["mask"] is not None:
+                    mask = torch.as_tensor(samples["mask"]).to(torch.bool).cpu().view(B, L)
+                else:
+                    rate = np.random.normal(0.5, 0.1)
+                    mask = RandomMaskingGenerator(L, float(np.clip(rate, 0.1, 0.7)), B)
+                self.mask = mask.unsqueeze(1)
+                kept = [torch.nonzero(~mask[b]).flatten().tolist() for b in range(B)]
+                self.mask_img_len = len(kept[0])
+                assert all(len(k) == self.mask_img_len for k in kept)
+            self.llama_tokenizer.padding_side = "right"
+            text = [t + self.llama_tokenizer.eos_token for t in answers_txt] if self.qformer_text_input \
+                else [t + self.end_sym for t in answers_txt]
+            tr = self.llama_tokenizer(text, return_tensors="pt", padding="longest", truncation=True,
+                                      max_length=self.max_txt_len, add_special_tokens=False)
+            answers = [tr.input_ids[b][: int(tr.attention_mask[b].sum())].tolist() for b in range(B)]
+            rows, attention_mask, targets = self._assemble(L, kept, instruction, answers, B)
+            plan = dict(rows=self._upload_rows(rows, dev), attention_mask=hip.with_host(attention_mask, dev), targets=hip.with_host(targets, dev))
+            if mask is not None:
+                urows, un_a, _ = self._assemble(L, [list(range(L))] * B, instruction, answers, B)
+                plan.update(urows=self._upload_rows(urows, dev), un_a=hip.with_host(un_a, dev))
+        # ---- device work: encode -> pooling -> ONE gather per sequence block ----------------------------------------------
+        img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
+        assert use_image_enc == use_image
+        if not use_image:
+            img_embeds = self.pool_video(img_embeds)
+        elif img_embeds.dim() == 3:
+            img_embeds = img_embeds.unsqueeze(1)
+        if own is not None:
             if not own:
                 return None
             if not getattr(self, "_fp_local_clips", False):   # (skipped all-gather: img_embeds holds exactly the owned clips already)
                 img_embeds = img_embeds[own].contiguous()
-            if instruction is not None and not isinstance(instruction, str):
-                instruction = [instruction[c] for c in own]
-            answers_txt = [answers_txt[c] for c in own]
-            if "mask" in samples and samples["mask"] is not None:
-                samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
-        B, _, L, D = img_embeds.shape
-        dev = img_embeds.device
-        kept = [list(range(L)) for _ in range(B)]
-        mask = None
-        if not use_image and self.use_mask:
-            self.img_len = L
-            if "mask" in samples and samples["mask"] is not None:
-                mask = torch.as_tensor(samples["mask"]).to(torch.bool).cpu().view(B, L)
-            else:
-                rate = np.random.normal(0.5, 0.1)
-                mask = RandomMaskingGenerator(L, float(np.clip(rate, 0.1, 0.7)), B)
-            self.mask = mask.unsqueeze(1)
-            kept = [torch.nonzero(~mask[b]).flatten().tolist() for b in range(B)]
-            self.mask_img_len = len(kept[0])
-            assert all(len(k) == self.mask_img_len for k in kept)
-        self.llama_tokenizer.padding_side = "right"
-        text = [t + self.llama_tokenizer.eos_token for t in answers_txt] if self.qformer_text_input \
-            else [t + self.end_sym for t in answers_txt]
-        tr = self.llama_tokenizer(text, return_tensors="pt", padding="longest", truncation=True,
-                                  max_length=self.max_txt_len, add_special_tokens=False)
-        answers = [tr.input_ids[b][: int(tr.attention_mask[b].sum())].tolist() for b in range(B)]
+        assert tuple(img_embeds.shape[:3]) == (B, 1, L), (tuple(img_embeds.shape), B, L)
+        D = img_embeds.shape[-1]
         vis_flat = img_embeds.reshape(B * L, D)
         if self._tape is not None:
             self._tape.update(vis_rows=B * L, pooled=not use_image)
-        rows, attention_mask, targets = self._assemble(L, kept, instruction, answers, B)
-        inputs_embeds = self._gather_tokens(vis_flat, rows)
+        inputs_embeds = self._gather_tokens(vis_flat, plan["rows"])
         un_e = un_a = None
-        if mask is not None:
-            urows, un_a, _ = self._assemble(L, [list(range(L))] * B, instruction, answers, B)
-            un_e = self._gather_tokens(vis_flat, urows)
-            un_a = hip.with_host(un_a, dev)
-        return inputs_embeds, hip.with_host(attention_mask, dev), un_e, un_a, hip.with_host(targets, dev)
+        if "urows" in plan:
+            un_e = self._gather_tokens(vis_flat, plan["urows"])
+            un_a = plan["un_a"]
+        return inputs_embeds, plan["attention_mask"], un_e, un_a, plan["targets"]
 
     @classmethod
     def from_config(cls, cfg, device=None):

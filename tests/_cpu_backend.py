@@ -376,6 +376,18 @@ def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=Non
     return LlamaModel.prefill_layers_per_op(_LM(x.shape[1], n_heads, eps), x, layers, B, S, rope[0], rope[1], kv_len, cache, dtype)
 
 
+def qformer_layer_array(layers):
+    return None
+
+
+def qformer_layers(hq32, hq16, ht32, ht16, enc16, layers, carr, *, n_seq, n_query, n_text, n_heads, dtype, kv_len=None):
+    """stllm_qformer_layers: the BertLayer loop, one contract call per op (what the C entry point issues)"""
+    import types
+    from stllm_amd.models.Qformer import BertModel
+    shim = types.SimpleNamespace(config=types.SimpleNamespace(hidden_size=hq32.shape[1], num_attention_heads=n_heads))
+    return BertModel.encode_layers_per_op(shim, layers, hq32, hq16, ht32, ht16, enc16, n_seq, n_query, n_text, kv_len, dtype)
+
+
 @contextlib.contextmanager
 def installed():
     """Monkey-patch stllm_amd.hip's compute entry points with the functions above (tests only)."""
@@ -384,7 +396,7 @@ def installed():
              "cross_entropy_rows", "cast_rows", "preprocess_frames", "transpose", "rmsnorm_bwd", "layernorm_bwd", "swiglu",
              "swiglu_bwd", "rope_bwd", "attention_bwd", "cross_entropy_bwd", "scatter_add_rows", "cosine_rows_bwd", "colsum",
              "relu_bwd", "gelu", "gelu_bwd", "scale_rows", "bcast_add_t", "adamw", "sumsq", "vit_block_array", "vit_blocks",
-             "llama_layer_array", "llama_layers"]
+             "llama_layer_array", "llama_layers", "qformer_layer_array", "qformer_layers"]
     saved = {n: getattr(hip, n) for n in names}
     try:
         for n in names:

@@ -31,7 +31,7 @@ def test_abi_exports_match_header():
     for name in sorted(declared):
         assert hasattr(L, name), f"libstllm_hip.so does not export {name}"
     assert set(hip.EXPORTS) == declared, (set(hip.EXPORTS) ^ declared)
-    assert L.stllm_abi_version() == 5
+    assert L.stllm_abi_version() == 6
 
 
 def test_phased_gemm_schedule_invariants():
