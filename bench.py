@@ -8,17 +8,17 @@ rendezvous on 127.0.0.1); under `python -m torch.distributed.run --nproc-per-nod
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it is given.  Rank 0 prints ONE JSON line.
 
 A "step" = one pass of the hot path over one batch of synthetic input (frames already resident in HBM):
-frames -> EVA-CLIP-g (39 blocks) -> ln_vision -> Q-Former (12 layers) -> llama_proj -> [N > 1: ONE RCCL all-gather of the
-projected visual tokens] -> pooling -> token-block assembly -> Vicuna-7B (32 layers) prefill -> lm_head (all positions) ->
-shifted CE.  Random-init weights (stllm_amd.synth), full sizes.
+frames -> EVA-CLIP-g (39 blocks) -> ln_vision -> Q-Former (12 layers) -> llama_proj -> [N > 1, a clip shared by a team of ranks:
+point-to-point exchange of the team's token sub-blocks] -> pooling -> token-block assembly -> Vicuna-7B (32 layers) prefill
+[sequence-parallel inside the team] -> lm_head (all positions) -> shifted CE.  Random-init weights (stllm_amd.synth), full sizes.
 
   --config c2 (default; BASELINE.json configs[1], the metric's configuration): per GPU one clip of T=16 frames, 'all' pooling
-      (512 video tokens), S = 576.  N > 1 = WEAK scaling: N clips per step; the N*16 frames are split into N contiguous
-      ranges (= one clip per rank), one all-gather, clip c prefilled on rank c.
+      (512 video tokens), S = 576.  N > 1 = WEAK scaling: N clips per step, one clip per rank (a team of one: nothing is exchanged).
   --config c3 (BASELINE.json configs[2]; reference config/instructblipbase_stllm_conversation.yaml:14-15,21): B=4 clips of
       T=64 frames, text-conditioned Q-Former, global-local 'residual' pooling R=16 (512 video tokens per clip), S ~ 580.
-      STRONG scaling: the same 4 x 64 frames at every N; frames sharded N ways (frame-parallel), one all-gather, clip c
-      prefilled on rank c % N (clip-parallel) — where the north star's ">= 6x at 8 GPUs" lives.
+      STRONG scaling: the same 4 x 64 frames at every N as clip teams (stllm_amd.parallel.TeamPlan): at N = 8 two ranks per clip, 32 frames
+      each, token sub-blocks exchanged point-to-point, the clip's prefill sequence-parallel over the pair — where the north star's
+      ">= 6x at 8 GPUs" lives.
   --config c4 (BASELINE.json configs[3]; reference st_llm.py:56-92, 480-493): T=32, 'all' pooling (1024 video tokens), dynamic masking
       (the mask the reference drew from numpy's RNG seeded with 1234: rate 0.547, 464 tokens kept) and the MVM branch: TWO prefills per
       step (S = 528 masked with lm_head + CE, S = 1088 un-masked), mvm_decoder + cosine loss.  One clip per GPU.
@@ -27,11 +27,11 @@ shifted CE.  Random-init weights (stllm_amd.synth), full sizes.
       c3 / c4 / c5 each have a full-size reference fixture (tests/golden/c{3,4,5}_full.npz): their lines carry `parity` like c2's.
   At N > 1 the default (c2) run ALSO carries the north star's frame-parallel experiment in the same invocation (no extra flag):
       after the c2 timing the ranks build config c3, rank 0 times it ALONE (1-GPU reference, the other ranks wait at a barrier),
-      then all N ranks time it frame-parallel with the all-gather inside the step -> "frame_parallel": {ms_per_step_1gpu,
-      ms_per_step, speedup, allgather_us, allgather_in_step: true, frames_per_rank, gathered_block_bit_identical}.
+      then all N ranks time it as clip teams -> "frame_parallel": {ms_per_step_1gpu, ms_per_step + speedup (steps back to back),
+      latency_ms + latency_speedup (one batch between barriers), plan, token_exchange_us, frames_per_rank, received_blocks_bit_identical}.
   At N = 1 (c2) the line also carries an fp16 leg, the fp32 "verify" leg and the SPLIT verify leg (bf16x3: three bf16 matrix-core products
       per Linear, fp32 everything else) — ms_per_step + parity each — next to the timed bf16, a `frame_parallel_projection` block (config c3
-      timed on this one GPU, then every rank's share at N = 2 / 4 / 8 timed alone on it: projected_ms = slowest share + a MODELLED all-gather),
+      timed on this one GPU, then every kind of rank at N = 2 / 4 / 8 played alone on it: throughput_ms and latency_ms from the measured shares + a MODELLED wire),
       the device's clock / power over the timed region (`telemetry`) and the timed region's per-block times (`ms_per_step_blocks`).
   --dry-cpu: plumbing check of the multi-rank code path on CPU (gloo, tests/_cpu_backend.py instead of the HIP library,
       reduced depth): NOT a measurement — used by tests/test_bench_cpu.py.
@@ -243,31 +243,55 @@ def numerics_legs(model, samples, args, sync):
     return out
 
 
-def frame_parallel_leg(args, world, rank, device, dry, sync):
-    """The north star's multi-GPU experiment, inside the default `--gpus N` run: BASELINE configs[2] (c3: B = 4 clips x T = 64 frames,
-    text-conditioned Q-Former, residual pooling R = 16; reference config/instructblipbase_stllm_conversation.yaml:14-15) under STRONG
-    scaling — rank 0 alone first (the 1-GPU reference), then the N ranks frame-parallel with ONE RCCL all-gather inside the step and
-    the prefill clip-parallel.  Also checks, once, that the gathered token block is bit-identical to one GPU encoding the same frame
-    ranges one after another (the collective moves bits; kernels are deterministic for a given launch shape)."""
-    from stllm_amd import parallel, runtime
+def _c3_setup(args, device):
     conf = CONFIGS["c3"]
     T = args.frames if args.frames else conf["frames"]
     mconf = dict(conf["model"])
     if mconf.get("residual_size", 0) > T:
         mconf["residual_size"] = T
     model = build_model(device, args, mconf)
-    sm = model.model.stllm_model
-    B = conf["clips"]
-    samples = make_samples(B, T, device, text=True)
+    B = args.fp_clips if getattr(args, "fp_clips", 0) else conf["clips"]
+    return model, model.model.stllm_model, make_samples(B, T, device, text=True), B, T, mconf
+
+
+def _encode_as_rank(sm, samples, plan, m, T, dt):
+    """{clip: tokens} exactly as rank m of the plan computes them: ALL its frame ranges in one encode call (same launch shapes -> same bits)"""
+    frames = samples["image"].reshape((-1,) + tuple(samples["image"].shape[2:]))
+    qtext = [it.split("Human: ")[1].split(" ###")[0] for it in samples["instruction_input"]]
+    all_t = [t for t in qtext for _ in range(T)]
+    enc = plan.encodes(m)
+    idx = [c * T + f for c, f0, f1 in enc for f in range(f0, f1)]
+    if not idx:
+        return {}
+    contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+    fr = frames[idx[0]: idx[0] + len(idx)] if contiguous else frames[torch.as_tensor(idx, device=frames.device)]
+    toks = sm._encode_frames(fr, [all_t[i] for i in idx], T, dt)
+    out, o = {}, 0
+    for c, f0, f1 in enc:
+        out[c] = toks[o: o + (f1 - f0)]
+        o += f1 - f0
+    return out
+
+
+def frame_parallel_leg(args, world, rank, device, dry, sync):
+    """The north star's multi-GPU experiment, inside the default `--gpus N` run: BASELINE configs[2] (c3: B = 4 clips x T = 64 frames,
+    text-conditioned Q-Former, residual pooling R = 16; reference config/instructblipbase_stllm_conversation.yaml:14-15) under STRONG
+    scaling — rank 0 alone first (the 1-GPU reference), then the N ranks as clip teams (stllm_amd.parallel.TeamPlan): a clip's frames are
+    encoded by its team, the token sub-blocks travel point-to-point inside the team, the clip's prefill runs sequence-parallel over the team.
+    Timed twice: back to back (`ms_per_step`: throughput, steps pipeline across ranks) and one batch at a time between barriers
+    (`latency_ms`).  Also checks, once, that the token blocks rank 0 received are bit-identical to one GPU encoding the same frame ranges."""
+    from stllm_amd import parallel, runtime
+    model, sm, samples, B, T, mconf = _c3_setup(args, device)
     n_frames = B * T
     steps1 = 1 if dry else args.fp_steps_1gpu
-    stepsN = 1 if dry else args.fp_steps
+    stepsN = 1 if dry else max(args.fp_steps, 30)      # >= 30: the pipeline's fill / drain is < 2 % of the bracket
+    stepsL = 1 if dry else 10
     # ---- 1 GPU: rank 0 alone -------------------------------------------------------------------------
     ms1 = 0.0
-    ref_tokens = None
+    ref_blocks = None
+    sm.set_frame_parallel(rank, world)
+    plan = sm._team_plan(B, T)
     sm.set_frame_parallel(0, 1)
-    load = sm._prefill_load(B, T, world)
-    ranges = [parallel.frame_range(n_frames, r, world, load) for r in range(world)]
     if rank == 0:
         for _ in range(1 if dry else 2):
             model(samples=samples)
@@ -277,14 +301,12 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
             model(samples=samples)
         sync_local(dry)
         ms1 = (time.perf_counter() - t0) / steps1 * 1e3
-        # one GPU encoding the N frame ranges one after another: same launch shapes as the N ranks -> the same bits
         dt = runtime.compute_dtype()
-        frames = samples["image"].reshape((-1,) + tuple(samples["image"].shape[2:]))
-        qtext = [it.split("Human: ")[1].split(" ###")[0] for it in samples["instruction_input"]]
-        all_t = [t for t in qtext for _ in range(T)]
-        ref_tokens = torch.cat([sm._encode_frames(frames[s:e], all_t[s:e], T, dt) for s, e in ranges if e > s], dim=0)
+        ref_blocks = {}
+        for c in plan.clips_of(0):      # the clips rank 0 prefills (a share of): every member's sub-block, computed as that member computes it
+            ref_blocks[c] = torch.cat([_encode_as_rank(sm, samples, plan, m, T, dt)[c] for m, (f0, f1) in zip(plan.team[c], plan.frames[c]) if f1 > f0], dim=0)
     sync()
-    # ---- N GPUs: frame-parallel, all-gather in the step, clip-parallel prefill ------------------------
+    # ---- N GPUs -----------------------------------------------------------------------------------------
     sm.set_frame_parallel(rank, world)
     sm._fp_keep_tokens = True
     sm._fp_last_tokens = None
@@ -295,52 +317,57 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
     ident, ident_err = None, None
     if rank == 0:
         got = sm._fp_last_tokens
-        want = ref_tokens
-        if got.shape[0] != n_frames:     # one clip per rank (N == number of clips): nothing is exchanged, the block is rank 0's own range
-            s0, e0 = ranges[0]
-            want = ref_tokens[s0:e0]
-        got = got.reshape(want.shape)
-        ref_tokens = want
-        ident = bool(torch.equal(got, ref_tokens))
-        ident_err = float((got - ref_tokens).abs().max().item())
+        ident = all(torch.equal(got[c].reshape(ref_blocks[c].shape), ref_blocks[c]) for c in ref_blocks)
+        ident_err = max(float((got[c].reshape(ref_blocks[c].shape) - ref_blocks[c]).abs().max().item()) for c in ref_blocks)
         if not (ident_err <= 1e-3):   # a wrong frame, a wrong rank order or a torn transfer: stop — the timing below would be of a broken path
-            raise RuntimeError(f"frame-parallel: gathered token block differs from the 1-GPU encode of the same frame ranges "
-                               f"(max abs diff {ident_err:.3e})")
+            raise RuntimeError(f"frame-parallel: a received token block differs from the 1-GPU encode of the same frame ranges (max abs diff {ident_err:.3e})")
     sm._fp_keep_tokens = False
     sm._fp_last_tokens = None
-    del ref_tokens
+    del ref_blocks
     sync()
     t0 = time.perf_counter()
     for _ in range(stepsN):
         out = model(samples=samples)
     sync()
     dtN = time.perf_counter() - t0
-    t = torch.tensor([dtN], device=device, dtype=torch.float64)
+    # ---- one batch at a time: barrier + synchronize around every step (what a single request sees) -------
+    lat = 0.0
+    for _ in range(stepsL):
+        sync()
+        t1 = time.perf_counter()
+        out = model(samples=samples)
+        sync()
+        lat += time.perf_counter() - t1
+    t = torch.tensor([dtN, lat], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    msN = float(t[0].item()) / stepsN * 1e3
-    # ---- the collective on its own (same shapes, same stream) ----------------------------------------
-    s0, e0 = ranges[rank]
-    local = torch.zeros((e0 - s0, 32, 4096), dtype=torch.float32, device=device)
-    for _ in range(3):
-        parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
-    sync()
-    t1 = time.perf_counter()
-    reps = 2 if dry else 20
-    for _ in range(reps):
-        parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
-    sync()
-    ag_us = (time.perf_counter() - t1) / reps * 1e6
-    counts = [e - s for s, e in ranges]
+    msN, msL = float(t[0].item()) / stepsN * 1e3, float(t[1].item()) / stepsL * 1e3
+    # ---- the token exchange on its own (same shapes, same stream) --------------------------------------
+    local = {c: torch.zeros((f1 - f0, 32, 4096), dtype=torch.float32, device=device) for c, f0, f1 in plan.encodes(rank)}
+    x_us = 0.0
+    if plan.exchange_needed():
+        for _ in range(3):
+            parallel.exchange_clip_tokens(local, plan, rank, device=device)
+        sync()
+        t1 = time.perf_counter()
+        reps = 2 if dry else 20
+        for _ in range(reps):
+            parallel.exchange_clip_tokens(local, plan, rank, device=device)
+        sync()
+        x_us = (time.perf_counter() - t1) / reps * 1e6
     R = mconf["residual_size"]
     res = {"config": "c3", "workload": f"BASELINE configs[2]: B={B} clips x T={T} frames, text-conditioned Q-Former, residual pooling R={R} "
                                        f"({R * 32} video tokens per clip), strong scaling (the same {n_frames} frames at every N)",
-           "scaling": "strong", "steps_1gpu": steps1, "steps": stepsN,
+           "scaling": "strong", "steps_1gpu": steps1, "steps": stepsN, "latency_steps": stepsL,
            "ms_per_step_1gpu": round(ms1, 3), "ms_per_step": round(msN, 3), "speedup": round(ms1 / msN, 3) if msN > 0 else None,
+           "latency_ms": round(msL, 3), "latency_speedup": round(ms1 / msL, 3) if msL > 0 else None,
            "video_tokens_per_s": round(B * R * 32 / (msN * 1e-3), 1), "frames_per_s": round(n_frames / (msN * 1e-3), 1),
-           "allgather_us": round(ag_us, 1), "allgather_in_step": bool(parallel.gather_needed(n_frames, T, world, load)),
-           "allgather_bytes_per_rank": max(counts) * 32 * 4096 * 4, "frames_per_rank": counts,
-           "clips_per_rank": [len(parallel.clips_of_rank(B, r, world)) for r in range(world)],
-           "gathered_block_bit_identical": ident, "gathered_block_max_abs_diff": ident_err}
+           "plan": plan.describe(), "sequence_parallel_prefill": bool(any(plan.sp)),
+           "token_exchange_us": round(x_us, 1), "token_exchange_in_step": bool(plan.exchange_needed()),
+           "token_exchange_bytes_sent_per_rank": [sum((f1 - f0) * 32 * 4096 * 4 * (len(plan.receivers(c)) - (1 if r in plan.receivers(c) else 0)) for c, f0, f1 in plan.encodes(r))
+                                                  for r in range(world)],
+           "frames_per_rank": [sum(f1 - f0 for _, f0, f1 in plan.encodes(r)) for r in range(world)],
+           "clips_per_rank": [len(plan.clips_of(r)) for r in range(world)],
+           "received_blocks_bit_identical": ident, "received_blocks_max_abs_diff": ident_err}
     del model
     return res
 
@@ -426,82 +453,92 @@ class Telemetry:
 XGMI_LINK_GBS_PER_DIR = 76.8   # MI355X: 7 xGMI links x ~153.6 GB/s bidirectional per GPU, fully connected 8-GPU node => one direct link per peer
 
 
+def model_p2p_ms(nbytes, efficiency=0.7, latency_us=30.0):
+    """MODELLED, not measured (no multi-GPU box in the build loop): one ncclSend / ncclRecv pair of `nbytes` over the direct xGMI link of its two ranks"""
+    return latency_us * 1e-3 + nbytes / (XGMI_LINK_GBS_PER_DIR * 1e9 * efficiency) * 1e3
+
+
 def model_allgather_ms(bytes_per_rank, world, efficiency=0.7, latency_us=50.0):
-    """MODELLED, not measured (no multi-GPU box in the build loop): the all-gather of `bytes_per_rank` from each of `world` ranks.
-    direct: every peer's chunk arrives on its own xGMI link, all links concurrently (what a fully connected node allows: 1 hop);
-    ring: (world - 1) steps over ONE link per direction (RCCL's ring algorithm: the pessimistic bound)."""
+    """MODELLED: the round 1-4 all-gather of `bytes_per_rank` from each of `world` ranks (fp_mode "allgather").
+    ring: (world - 1) steps over ONE link per direction (RCCL's default algorithm, the figure to plan with); direct: every peer's chunk on its own link."""
     bw = XGMI_LINK_GBS_PER_DIR * 1e9 * efficiency
     direct = latency_us * 1e-3 + bytes_per_rank / bw * 1e3
     ring = latency_us * 1e-3 + (world - 1) * bytes_per_rank / bw * 1e3
-    return {"direct_ms": round(direct, 3), "ring_ms": round(ring, 3),
-            "assumptions": f"modelled (xGMI 1-hop: {XGMI_LINK_GBS_PER_DIR} GB/s per link and direction x {efficiency} efficiency, {latency_us:.0f} us launch + sync latency)"}
+    return {"ring_ms": round(ring, 3), "direct_ms": round(direct, 3),
+            "assumptions": f"modelled (xGMI: {XGMI_LINK_GBS_PER_DIR} GB/s per link and direction x {efficiency} efficiency, {latency_us:.0f} us launch + sync latency)"}
 
 
 def frame_parallel_projection(args, device):
-    """N = 1 only: ground the 8-GPU frame-parallel claim on ONE GPU.  Config c3 (B = 4 clips x T = 64 frames, text Q-Former,
-    residual R = 16; STRONG scaling) is timed whole on this GPU; then, for N = 2 / 4 / 8, the share of every KIND of rank (parallel.frame_counts
-    ranges: its frame range's encode + the prefill of the clips it owns) is timed ALONE on this GPU, the all-gather replaced by a device copy
-    into a pre-computed token block (STLLMModel._fp_sim_tokens) -> projected_ms = slowest share + the MODELLED collective."""
+    """N = 1 only: ground the 8-GPU claim on ONE GPU (UNMEASURED on a multi-GPU node: the driver's SCALE run is the measurement).  Config c3
+    (B = 4 clips x T = 64 frames, text Q-Former, residual R = 16; STRONG scaling) is timed whole on this GPU; then, for N = 2 / 4 / 8, every KIND
+    of rank of the TeamPlan is played alone on this GPU — its frame ranges' encode, then its (share of the) prefill, receives replaced by
+    parallel.Mailbox(dummy) — and timed twice: the encode alone (`enc_ms`) and the whole step (`step_ms`).  From those and a MODELLED wire:
+        throughput_ms = max over ranks of step_ms + exchange            (steps back to back: no rank waits for another team)
+        latency_ms    = max over clips of [max over the team of enc_ms + token exchange + max over its prefill ranks of (step_ms - enc_ms) + K|V lag]
+    i.e. the critical path of ONE batch: a clip's prefill starts when ITS team's frames are in, not when the node's are."""
     from stllm_amd import parallel, runtime
-    conf = CONFIGS["c3"]
-    T, B = (args.frames if args.frames else conf["frames"]), conf["clips"]
-    mconf = dict(conf["model"])
-    if mconf.get("residual_size", 0) > T:
-        mconf["residual_size"] = T
-    model = build_model(device, args, mconf)
-    sm = model.model.stllm_model
-    samples = make_samples(B, T, device, text=True)
-    n_frames = B * T
+    model, sm, samples, B, T, mconf = _c3_setup(args, device)
 
-    def timed(steps, warm):
+    def timed(fn, steps, warm):
         for _ in range(warm):
-            model(samples=samples)
+            fn()
         sync_local(args.dry_cpu)
         t0 = time.perf_counter()
         for _ in range(steps):
-            model(samples=samples)
+            fn()
         sync_local(args.dry_cpu)
         return (time.perf_counter() - t0) / steps * 1e3
-    steps1, stepsN = (1, 1) if args.dry_cpu else (args.fp_steps_1gpu, max(3, args.fp_steps // 2))
+    steps1, stepsN = (1, 1) if args.dry_cpu else (args.fp_steps_1gpu, 5)
     sm.set_frame_parallel(0, 1)
-    ms1 = timed(steps1, 1 if args.dry_cpu else 2)
-    dt = runtime.compute_dtype()
-    frames = samples["image"].reshape((-1,) + tuple(samples["image"].shape[2:]))
+    ms1 = timed(lambda: model(samples=samples), steps1, 1 if args.dry_cpu else 2)
     qtext = [it.split("Human: ")[1].split(" ###")[0] for it in samples["instruction_input"]]
-    all_t = [t for t in qtext for _ in range(T)]
-    sm._fp_sim_tokens = sm._encode_frames(frames, all_t, T, dt)      # what the all-gather delivers: [B * T, 32, 4096] fp32
+    S = int(model(samples=samples).logits.shape[1])
     per_n = {}
     try:
         for N in (2, 4, 8):
-            load = sm._prefill_load(B, T, N)
-            counts = parallel.frame_counts(n_frames, N, load)
-            kind = lambda r: (counts[r], len(parallel.clips_of_rank(B, r, N)))
-            shares = []
+            sm.set_frame_parallel(0, N, mailbox=parallel.Mailbox(dummy=True))
+            plan = sm._team_plan(B, T)
+
+            def kind(r):
+                return (tuple((f1 - f0) for _, f0, f1 in plan.encodes(r)), tuple((plan.member_index(c, r), len(plan.team[c]), plan.sp[c]) for c in plan.clips_of(r)))
+            meas = {}
             for k in sorted(set(kind(r) for r in range(N))):
                 r = min(q for q in range(N) if kind(q) == k)
-                sm.set_frame_parallel(r, N)
-                ms = timed(stepsN, 1)
-                shares.append({"rank": r, "ranks_of_this_kind": sum(1 for q in range(N) if kind(q) == k), "frames": k[0], "clips_prefilled": k[1],
-                               "ms": round(ms, 3)})
-            gather = bool(parallel.gather_needed(n_frames, T, N, load))
-            ag = model_allgather_ms(max(counts) * 32 * 4096 * 4, N) if gather else None
-            slow = max(sh["ms"] for sh in shares)
-            proj = slow + (ag["direct_ms"] if ag else 0.0)
-            per_n[str(N)] = {"frames_per_rank": counts, "shares": shares, "allgather_needed": gather,
-                             "allgather_bytes_per_rank": max(counts) * 32 * 4096 * 4 if gather else 0, "allgather_model": ag,
-                             "projected_ms": round(proj, 3), "projected_speedup": round(ms1 / proj, 3),
-                             "projected_speedup_ring_allgather": round(ms1 / (slow + (ag["ring_ms"] if ag else 0.0)), 3),
-                             "sum_of_shares_over_1gpu": round(sum(sh["ms"] * sh["ranks_of_this_kind"] for sh in shares) / ms1, 3)}
+                sm.set_frame_parallel(r, N, mailbox=parallel.Mailbox(dummy=True))
+                enc_ms = timed(lambda: sm.encode_img(samples["image"], qtext), stepsN, 1)
+                step_ms = timed(lambda: model(samples=samples), stepsN, 1)
+                meas[k] = (enc_ms, step_ms)
+            tok_ms = sp_lag = 0.0
+            if plan.exchange_needed():
+                tok_ms = max(model_p2p_ms((f1 - f0) * 32 * 4096 * 4) for c in range(B) for f0, f1 in plan.frames[c] if f1 > f0)   # the pairs run concurrently, each on its own link
+            if any(plan.sp):
+                kmax = max(len(plan.team[c]) for c in range(B) if plan.sp[c])
+                sp_lag = (kmax - 1) * model_p2p_ms(S // kmax * 2 * 4096 * 2)     # member j trails member j - 1 by one K | V hand-over; the last layer's is exposed
+            lat = 0.0
+            for c in range(B):
+                enc = max(meas[kind(m)][0] for m in plan.team[c])
+                pre = max(meas[kind(m)][1] - meas[kind(m)][0] for m in (plan.team[c] if plan.sp[c] else plan.team[c][:1]))
+                lat = max(lat, enc + (tok_ms if len(plan.team[c]) > 1 else 0.0) + pre + (sp_lag if plan.sp[c] else 0.0))
+            thr = max(v[1] for v in meas.values()) + tok_ms + sp_lag
+            shares = [{"ranks_of_this_kind": sum(1 for q in range(N) if kind(q) == k), "frames": list(k[0]),
+                       "prefill": [{"member": j, "team_size": kk, "sequence_parallel": bool(spf)} for j, kk, spf in k[1]],
+                       "enc_ms": round(v[0], 3), "step_ms": round(v[1], 3)} for k, v in sorted(meas.items())]
+            per_n[str(N)] = {"plan": plan.describe(), "shares": shares, "token_exchange_ms_modelled": round(tok_ms, 3), "kv_lag_ms_modelled": round(sp_lag, 3),
+                             "throughput_ms": round(thr, 3), "throughput_speedup": round(ms1 / thr, 3),
+                             "latency_ms": round(lat, 3), "latency_speedup": round(ms1 / lat, 3),
+                             "projected_ms": round(thr, 3), "projected_speedup": round(ms1 / thr, 3),
+                             "sum_of_shares_over_1gpu": round(sum(meas[kind(q)][1] for q in range(N)) / ms1, 3)}
     finally:
-        sm._fp_sim_tokens = None
         sm.set_frame_parallel(0, 1)
     R = mconf["residual_size"]
     res = {"config": "c3", "workload": f"BASELINE configs[2]: B={B} clips x T={T} frames, text-conditioned Q-Former, residual pooling R={R}, strong scaling",
-           "method": "measured on ONE GPU: the whole batch, then each kind of rank's share alone (its frame range's encode + the prefill of its clips; the "
-                     "all-gather replaced by a device copy into a pre-computed token block); projected_ms = slowest share + MODELLED all-gather",
+           "status": "UNMEASURED on a multi-GPU node — measured shares of ONE GPU + a modelled wire",
+           "method": "measured on ONE GPU: the whole batch, then each kind of rank of the TeamPlan alone (its frames' encode; its share of its clip's prefill, "
+                     "sequence-parallel inside the clip's team; receives are no-ops); throughput_ms = slowest rank's step + exchange, latency_ms = critical path of one batch",
+           "wire_model": f"point-to-point over the pair's direct xGMI link: {XGMI_LINK_GBS_PER_DIR} GB/s per direction x 0.7 + 30 us per transfer (no ring: ncclSend / ncclRecv)",
            "steps_1gpu": steps1, "steps_per_share": stepsN, "ms_per_step_1gpu": round(ms1, 3), "n": per_n,
            "sum_of_shares_note": "sum_of_shares_over_1gpu > 1 = work lost to the smaller per-rank batches (GEMM tile quantisation at M = frames x 257, "
-                                 "one un-split prefill per owning rank)"}
+                                 "the prefill's GEMMs at M = S / team size)"}
     del model
     return res
 
@@ -607,7 +644,7 @@ def _run(args, world, rank, device, dry):
         out = step()
     sync()
     own = getattr(sm, "owned_clips", list(range(B))) if world > 1 else list(range(B))
-    S_local = out.logits.shape[1] if out.logits is not None else 0
+    S_local = (out.sp_rows[1] if getattr(out, "sp_rows", None) else out.logits.shape[1]) if out.logits is not None else 0   # (sequence-parallel: the clip's length = the last member's end)
     S_un = (S_local - sm.mask_img_len + sm.img_len) if (mask is not None and out.logits is not None) else 0   # the MVM branch's second prefill
     parity = None
     if rank == 0 and out.logits is not None and world == 1 and not dry and B == (conf["clips"] or 1):
@@ -661,24 +698,9 @@ def _run(args, world, rank, device, dry):
     loss = float(out.loss.item()) if out.loss is not None else float("nan")
     bt = conf["model"].get("vit_model") == "eva_btadapter_g"
 
-    # ---- the collective on its own: the all-gather of the projected tokens, same shape, same stream ----
-    ag_us = None
-    prefill_load = sm._prefill_load(B, T, world)
-    if world > 1:
-        from stllm_amd import parallel
-        n_frames = B * T
-        load = sm._prefill_load(B, T, world)
-        s0, e0 = parallel.frame_range(n_frames, rank, world, load)
-        local = torch.zeros((e0 - s0, 32, 4096), dtype=torch.float32, device=device)
-        for _ in range(3):
-            parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
-        sync()
-        t1 = time.perf_counter()
-        reps = 2 if dry else 20
-        for _ in range(reps):
-            parallel.all_gather_frames(local, n_frames, rank, world, extra=load)
-        sync()
-        ag_us = (time.perf_counter() - t1) / reps * 1e6
+    plan_desc = None
+    if world > 1 and sm.vit_model == "eva_clip_g":
+        plan_desc = sm._team_plan(B, T)
 
     extra_legs = fp_leg = None
     if world == 1 and args.config == "c2" and not dry and not args.no_extra_legs and parity is not None:
@@ -704,8 +726,8 @@ def _run(args, world, rank, device, dry):
         Lt = 24 if text else 0
         flop_clip = algorithmic_flops(T, S, Lt, S_unmasked=S_un, btadapter=bt)
         step_s = dt_s / args.steps
-        par = "single GPU" if world == 1 else (f"frame-parallel x{world} (contiguous frame ranges) + ONE RCCL all-gather of [frames/{world}, 32, 4096] fp32 + "
-                                               f"clip-parallel prefill (clip c on rank c % {world})")
+        par = "single GPU" if world == 1 else (f"clip teams over {world} ranks (stllm_amd.parallel.TeamPlan): a clip's frames encoded by its team, token sub-blocks "
+                                               f"point-to-point inside the team, prefill sequence-parallel over the team")
         names = CONFIG_NAMES
         res = {"metric": f"video-tokens/sec (ViT+Qformer+LLM-prefill) at T={T}, Vicuna-7B", "value": round(B * Lvis / step_s, 2),
                "unit": "video-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -723,18 +745,15 @@ def _run(args, world, rank, device, dry):
                "algorithmic_tflop_per_step": round(B * flop_clip / 1e12, 3),
                "end_to_end_tflops_per_gpu": round(B * flop_clip / step_s / 1e12 / world, 1)}
         if world > 1:
-            res["allgather_us"] = round(ag_us, 1)
-            counts = parallel.frame_counts(B * T, world, prefill_load)
-            res["frames_per_rank"] = counts     # levelled against the prefill load of each rank (stllm_amd.parallel.frame_counts)
-            res["allgather_bytes_per_rank"] = max(counts) * 32 * 4096 * 4
-            # one clip per GPU: every rank's frames are the clip it prefills, the collective is skipped inside the step (allgather_us
-            # is the stand-alone timing of what it would cost)
-            res["allgather_in_step"] = bool(parallel.gather_needed(B * T, T, world, prefill_load))
+            if plan_desc is not None:
+                res["plan"] = plan_desc.describe()
+                res["frames_per_rank"] = [sum(f1 - f0 for _, f0, f1 in plan_desc.encodes(r)) for r in range(world)]
+                res["token_exchange_in_step"] = bool(plan_desc.exchange_needed())
             res["rccl_ranks"] = dist.get_world_size()
             if conf["scaling"] == "weak":
-                res["scaling_note"] = ("c2 at N > 1 is weak scaling (one clip per GPU; each rank's frame range is its own clip, so the all-gather "
-                                       "would carry no remote token the prefill needs and is skipped: allgather_in_step false); the frame-parallel "
-                                       "strong-scaling experiment (config c3, all-gather inside the step) is the frame_parallel block of this line")
+                res["scaling_note"] = ("weak scaling: one clip per GPU — every rank is a clip team of one, nothing is exchanged inside the step "
+                                       "(token_exchange_in_step false); the frame-parallel strong-scaling experiment (config c3: clip teams, point-to-point "
+                                       "exchange, sequence-parallel prefill) is the frame_parallel block of this line")
             if fp_leg is not None:
                 res["frame_parallel"] = fp_leg
         if dry:
@@ -800,7 +819,8 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the fp16 and fp32-verify legs after the timed region")
     ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the c3 frame-parallel strong-scaling block")
     ap.add_argument("--no-projection", action="store_true", help="N = 1: skip the frame_parallel_projection block (c3 and its per-rank shares on this GPU)")
-    ap.add_argument("--fp-steps", type=int, default=10, help="timed steps of the c3 block on N ranks")
+    ap.add_argument("--fp-steps", type=int, default=30, help="timed steps of the c3 block on N ranks (at least 30: pipeline fill / drain < 2 % of the bracket)")
+    ap.add_argument("--fp-clips", type=int, default=0, help="override the c3 block's clips per batch (debugging / dry runs: 1 clip on 2 ranks = one team of two)")
     ap.add_argument("--fp-steps-1gpu", type=int, default=3, help="timed steps of the c3 block's 1-GPU reference (rank 0 alone)")
     ap.add_argument("--dry-cpu", action="store_true", help="run the rank logic on CPU (gloo, contract backend): plumbing check only")
     args = ap.parse_args()

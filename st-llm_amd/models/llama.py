@@ -203,6 +203,64 @@ class LlamaModel(nn.Module):
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
         return x
 
+    def prefill_sp(self, inputs_embeds, sp):
+        """Sequence-parallel prefill of ONE sequence inside a clip team (stllm_amd.parallel, round 5): this rank runs the decoder layers on the
+        positions [s0, s1) = parallel.sp_row_ranges(S, k)[j] only.  Causal attention makes the team's dependency one-directional: per layer the
+        K | V rows of the members before this one arrive point-to-point (posted before this rank's own QKV GEMM, awaited in front of its
+        attention), its own K | V rows leave for the members behind it right after the QKV GEMM — the transfers ride under the o_proj / MLP
+        GEMMs of the sender and the RMSNorm / QKV GEMM of the receiver.  No kernel knows about any of this: the fused QKV buffer simply has rows
+        [0, s1) — foreign K | V, own q | k | v — and the attention runs causal over s1 x s1 (the s0 foreign query rows are zero, their outputs unused:
+        +7 us per layer at S = 580, k = 2, against a second set of attention kernels with a query offset).
+        sp: dict(index=j, size=k, ranks=[global ranks of the team], rank=this rank, group=None, mailbox=None | parallel.Mailbox).
+        inputs_embeds f32 [1, S, D] (every member assembles the whole sequence: one 9.5 MB gather).  Returns (hidden f32 [1, s1 - s0, D] after
+        model.norm, the same rows in the compute dtype, (s0, s1))."""
+        from .. import parallel
+        cfg = self.config
+        dt = runtime.compute_dtype()
+        layers = self.pack(dt)
+        B, S, D = inputs_embeds.shape
+        if B != 1:
+            raise NotImplementedError("sequence-parallel prefill: one sequence per team (stllm_amd.parallel.TeamPlan)")
+        H = cfg.num_attention_heads
+        hd = D // H
+        dev = inputs_embeds.device
+        j, k, ranks, me, group, box = sp["index"], sp["size"], sp["ranks"], sp["rank"], sp.get("group"), sp.get("mailbox")
+        rr = parallel.sp_row_ranges(S, k)
+        s0, s1 = rr[j]
+        x = inputs_embeds.reshape(S, D)[s0:s1].float().clone()
+        cos, sin = self.rope(S, dev)
+        cos_l, sin_l = cos[s0:s1], sin[s0:s1]
+        qkv = torch.empty((s1, 3 * D), device=dev, dtype=dt)
+        if s0 > 0:
+            qkv[:s0, :D].zero_()          # query columns of the foreign rows: never written again, their attention outputs are never read
+        n_loc = s1 - s0
+        if n_loc == 0:                     # more members than 32-row groups: this member has no rows (and nobody waits for any from it)
+            return x.view(1, 0, D), x.to(dt), (s0, s1)
+        pending = []                       # send handles + the packed buffers they read: kept until the end of the prefill
+        for li_, pk in enumerate(layers):
+            recvs = [(torch.empty((rr[i][1] - rr[i][0], 2 * D), device=dev, dtype=dt), ranks[i], ("kv", li_)) for i in range(j) if rr[i][1] > rr[i][0]]
+            works = parallel.p2p_exchange([], recvs, me, group, box) if recvs else []
+            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
+            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos_l, sin_l), rope_seq=n_loc, rope_cols=2 * D, out=qkv[s0:s1])
+            later = [i for i in range(j + 1, k) if rr[i][1] > rr[i][0]]
+            if later:
+                kv = qkv[s0:s1, D:].contiguous()
+                pending.append((kv, parallel.p2p_exchange([(kv, ranks[i], ("kv", li_)) for i in later], [], me, group, box)))
+            for w in works:
+                w.wait()
+            for (buf, _, _), i in zip(recvs, [i for i in range(j) if rr[i][1] > rr[i][0]]):
+                qkv[rr[i][0]:rr[i][1], D:].copy_(buf)
+            a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=1, H=H, Sq=s1, Skv=s1, D=hd, scale=hd ** -0.5, causal=True)
+            hip.gemm(a[s0:s1], pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+            h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
+            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+        for _, ws in pending:
+            for w in ws:
+                w.wait()
+        h16, h32 = hip.rmsnorm(x, self.norm.weight, cfg.rms_norm_eps, dtype=dt, want_f32=True)
+        return h32.view(1, n_loc, D), h16, (s0, s1)
+
     def decode_step(self, x_new, cache):
         """One token per sequence: x_new f32 [B,1,D] (embedding of the token at position cache.len).  Appends its K/V to the
         cache and returns (hidden f32 [B,1,D] after model.norm, hidden compute-dtype [B,D])."""
@@ -249,9 +307,16 @@ class LlamaModel(nn.Module):
         return KVCache(len(self.layers), batch, max_len, self.config.hidden_size, runtime.compute_dtype(), device)
 
     def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, use_cache=False,
-                output_hidden_states=False, return_dict=True, past_key_values=None, **kw):
+                output_hidden_states=False, return_dict=True, past_key_values=None, sp=None, **kw):
         if inputs_embeds is None:
             inputs_embeds = self.embed_tokens(input_ids)
+        if sp is not None:   # this rank's position range of a sequence-parallel prefill (no cache: generate() prefills on one GPU)
+            if use_cache or past_key_values is not None:
+                raise NotImplementedError("sequence-parallel prefill does not fill a KV cache")
+            hidden, h16, rows = self.prefill_sp(inputs_embeds, sp)
+            out = Output(last_hidden_state=hidden, past_key_values=None, hidden_states=(hidden,) if output_hidden_states else None, attentions=None)
+            out._h16, out._sp_rows = h16, rows
+            return out
         if isinstance(past_key_values, KVCache) and past_key_values.len > 0:   # decode step(s), one token at a time
             hs = []
             for t in range(inputs_embeds.shape[1]):

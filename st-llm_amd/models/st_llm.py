@@ -101,13 +101,43 @@ class STLLMModel(Blip2Base):
         self.embed_tokens = None  # set by STLLMLlamaModel.initialize_vision_modules (st_llm.py:54)
         self.frame_parallel = None  # (rank, world, group): see stllm_amd.parallel
         self._fp_local_clips = False
+        # how the ranks share a batch (stllm_amd.parallel): "team" = clip teams, point-to-point exchange per clip, sequence-parallel prefill inside a team
+        # (round 5) | "allgather" = flat frame ranges + ONE padded all-gather, the clip's owner prefills alone (rounds 1-4: kept as the fallback exchange)
+        self.fp_mode, self.fp_sp, self.fp_balance, self.fp_mailbox = "team", True, "latency", None
+        self._sp_state = None
 
-    def set_frame_parallel(self, rank, world, group=None):
-        """Shard the work of a batch over `world` GPUs.  eva_clip_g: the per-frame encode is split into contiguous frame
-        ranges (one all-gather of visual tokens), the prefill goes by clip.  BT-Adapter backbone: its temporal attention and
-        CLS averaging couple the T frames of a clip (eva_btadapter.py:162-169, 189-190), so the unit of work is the whole
-        clip — rank r encodes AND prefills the clips c with c % world == r, no collective (SURVEY.md §8e "shard by clip")."""
+    def set_frame_parallel(self, rank, world, group=None, mode=None, sp=None, balance=None, mailbox=None):
+        """Shard the work of a batch over `world` GPUs (stllm_amd.parallel).  eva_clip_g: the frames of a clip are encoded by the clip's TEAM
+        of ranks, the token sub-blocks are exchanged point-to-point inside the team and the clip's prefill runs sequence-parallel over the team
+        (mode "team", the default) — or, mode "allgather", flat frame ranges + one all-gather + owner-only prefill as in rounds 1-4.
+        BT-Adapter backbone: its temporal attention and CLS averaging couple the T frames of a clip (eva_btadapter.py:162-169, 189-190), so the
+        unit of work is the whole clip — rank r encodes AND prefills the clips c with c % world == r, no collective (SURVEY.md §8e "shard by
+        clip").  mailbox: a parallel.Mailbox standing in for the wire when one process plays the ranks one after another (tests, bench.py's shares)."""
         self.frame_parallel = (rank, world, group) if world > 1 else None
+        if mode is not None:
+            assert mode in ("team", "allgather")
+            self.fp_mode = mode
+        if sp is not None:
+            self.fp_sp = bool(sp)
+        if balance is not None:
+            assert balance in ("latency", "throughput")
+            self.fp_balance = balance
+        self.fp_mailbox = mailbox
+        self._sp_state = None
+
+    def _team_plan(self, n_clips, T):
+        """the TeamPlan of a batch of n_clips x T frames on this model's ranks.  The prefill is shared inside a team (sequence-parallel) unless the
+        forward needs two prefills and a loss over rows of both (MVM: use_mask, st_llm.py:71-91) — then the owner prefills alone."""
+        from .. import parallel
+        _, world, _ = self.frame_parallel
+        if self.video_input == "residual":
+            lvis = self.residual_size * 32
+        elif self.video_input == "mean":
+            lvis = 32
+        else:
+            lvis = T * 32
+        return parallel.TeamPlan(n_clips, T, world, sp=self.fp_sp and not self.use_mask, balance=self.fp_balance,
+                                 prefill_cost_frames=self.prefill_cost_frames * (lvis + 64) / 576.0)
 
     # encode time of one frame = 1; one prefilled clip of ~576 positions costs about this many frames; used to level the frame ranges when a
     # batch has fewer clips than ranks.  Measured on one MI355X (round 4, bench.py frame_parallel_projection, config 3 at N = 8): a rank
@@ -147,6 +177,42 @@ class STLLMModel(Blip2Base):
         T = image.shape[1]
         infer = image.dim() == 4
         use_image = True if T == 1 or infer else False
+        if self.frame_parallel is not None and not infer and self.vit_model == "eva_clip_g" and self.fp_mode == "team" and not use_image:
+            # clip teams (stllm_amd.parallel): this rank encodes its sub-ranges of its teams' clips in ONE batch, the sub-blocks travel
+            # point-to-point to the team members that prefill the clip; the result holds exactly the clips this rank prefills (a share of)
+            from .. import parallel
+            rank, world, group = self.frame_parallel
+            B = image.shape[0]
+            plan = self._team_plan(B, T)
+            frames = image.reshape((-1,) + tuple(image.shape[2:]))
+            enc = plan.encodes(rank)
+            local = {}
+            if enc:
+                idx = [c * T + f for c, f0, f1 in enc for f in range(f0, f1)]
+                contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+                fr = frames[idx[0]: idx[0] + len(idx)] if contiguous else frames[torch.as_tensor(idx, device=frames.device)]
+                t_local = None
+                if self.qformer_text_input:
+                    all_t = [text] * frames.shape[0] if isinstance(text, str) else [t for t in text for _ in range(T)]
+                    t_local = [all_t[i] for i in idx]
+                toks = self._encode_frames(fr, t_local, T, dt)
+                o = 0
+                for c, f0, f1 in enc:
+                    local[c] = toks[o: o + (f1 - f0)]
+                    o += f1 - f0
+            blocks = parallel.exchange_clip_tokens(local, plan, rank, group, self.fp_mailbox, device=image.device)
+            need = plan.clips_of(rank)
+            self._fp_local_clips = True
+            if getattr(self, "_fp_keep_tokens", False):   # bench.py / tests: the blocks as they arrived, per clip
+                self._fp_last_tokens = {c: blocks[c] for c in need}
+            if not need:
+                inputs_llama = torch.zeros((0, T, 32, 4096), dtype=torch.float32, device=image.device)
+            elif len(need) == 1:
+                inputs_llama = blocks[need[0]].view(1, T, -1, 4096)
+            else:
+                inputs_llama = torch.stack([blocks[c] for c in need], dim=0)
+            atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
+            return inputs_llama, atts_llama, use_image
         if self.frame_parallel is not None and not infer and self.vit_model == "eva_clip_g":
             from .. import parallel
             rank, world, group = self.frame_parallel
@@ -317,6 +383,7 @@ class STLLMModel(Blip2Base):
         else:
             qtext = None
         clip_sharded = False
+        self._sp_state = None
         if self.frame_parallel is not None and self.vit_model != "eva_clip_g" and image.dim() == 5:
             # BT-Adapter: clip-parallel from the first kernel on — this rank's clips only, then the single-GPU path
             from .. import parallel
@@ -355,8 +422,16 @@ class STLLMModel(Blip2Base):
         if self.frame_parallel is not None and not use_image and not clip_sharded:
             # clip-parallel prefill: this rank continues with the clips it owns (clip c -> rank c % world)
             from .. import parallel
-            rank, world, _ = self.frame_parallel
-            own = parallel.clips_of_rank(image.shape[0], rank, world)
+            rank, world, group = self.frame_parallel
+            self._sp_state = None
+            if self.fp_mode == "team" and self.vit_model == "eva_clip_g":
+                plan = self._team_plan(image.shape[0], T)
+                own = plan.clips_of(rank)
+                if len(own) == 1 and plan.sp[own[0]]:    # this rank runs ITS position range of the clip's prefill (LlamaModel.prefill_sp)
+                    team = plan.team[own[0]]
+                    self._sp_state = dict(index=team.index(rank), size=len(team), ranks=team, rank=rank, group=group, mailbox=self.fp_mailbox)
+            else:
+                own = parallel.clips_of_rank(image.shape[0], rank, world)
             self.owned_clips = own
             if own:
                 if instruction is not None and not isinstance(instruction, str):
@@ -477,7 +552,7 @@ class STLLMLlamaModel(LlamaModel):
             return None, None, None
         inputs_embeds, attention_mask, un_e, un_a, labels = res
         outputs = super().forward(attention_mask=attention_mask, inputs_embeds=inputs_embeds, use_cache=False,
-                                  output_hidden_states=un_e is not None, return_dict=True)
+                                  output_hidden_states=un_e is not None, return_dict=True, sp=sm._sp_state if un_e is None else None)
         if un_e is None:
             return outputs, None, labels
         # ---- MVM branch (st_llm.py:71-91) ---------------------------------------------------------
@@ -548,6 +623,35 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
         B, S, _ = outputs.last_hidden_state.shape
         logits = self.logits_from(outputs._h16, B, S)
         loss = None
+        sp_rows = getattr(outputs, "_sp_rows", None)   # sequence-parallel prefill: this rank holds the positions [s0, s1) of the clip only
+        if sp_rows is not None and labels is not None:
+            # lm_head + CE follow the rows.  The clip's loss is the sum over the team's row losses, accumulated along the team (member j adds its
+            # rows to what member j - 1 sent and passes the sum on): complete on the LAST member — which also holds the answer positions.
+            from .. import parallel
+            sp = self.model.stllm_model._sp_state
+            s0, s1 = sp_rows
+            lab_h = hip.host_mask(labels)
+            shift_h = torch.full_like(lab_h, -100)
+            shift_h[:, :-1] = lab_h[:, 1:]
+            part = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+            if S > 0:
+                rows = hip.cross_entropy_rows(logits.reshape(B * S, -1), hip.h2d(shift_h[:, s0:s1].reshape(-1).to(torch.int32), logits.device))
+                part = (rows.sum() / max(int((shift_h != -100).sum()), 1)).reshape(1)
+            j, k, ranks = sp["index"], sp["size"], sp["ranks"]
+            if j > 0:
+                prev = torch.zeros_like(part)
+                for w in parallel.p2p_exchange([], [(prev, ranks[j - 1], ("loss", 0))], sp["rank"], sp.get("group"), sp.get("mailbox")):
+                    w.wait()
+                part = part + prev
+            if j + 1 < k:
+                for w in parallel.p2p_exchange([(part, ranks[j + 1], ("loss", 0))], [], sp["rank"], sp.get("group"), sp.get("mailbox")):
+                    w.wait()
+            hip.gemm_workspace_check(logits.device) if logits.is_cuda else None
+            res = Output(loss=part[0], logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
+            object.__setattr__(res, "loss_mvm", None)
+            object.__setattr__(res, "sp_rows", (s0, s1))            # logits = rows [s0, s1) of the clip's sequence
+            object.__setattr__(res, "loss_complete", j + 1 == k)    # loss = the clip's loss on the last member, a partial sum before it
+            return res
         if labels is not None:  # shifted CE (st_llm.py:125-135)
             lab_h = getattr(labels, "_stllm_host", None)
             if lab_h is not None:   # the targets were built on the host (st_llm.py:532-542): shift them there, one asynchronous H2D copy

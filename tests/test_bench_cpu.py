@@ -1,5 +1,5 @@
-"""CPU (gloo, world_size 2): bench.py's own multi-rank code path — self-spawned ranks, frame-parallel encode, the all-gather,
-clip-parallel prefill, max-over-ranks timing, the JSON contract — at reduced depth on the contract backend (`--dry-cpu`).
+"""CPU (gloo, world_size 2): bench.py's own multi-rank code path — self-spawned ranks, clip teams (frame-parallel encode, point-to-point
+token exchange, sequence-parallel prefill), max-over-ranks timing, the JSON contract — at reduced depth on the contract backend (`--dry-cpu`).
 A plumbing check: the numbers mean nothing, the structure of the line and the absence of a launcher requirement do."""
 import json
 import os
@@ -23,52 +23,54 @@ def _run(extra, timeout=900):
 
 @pytest.mark.parametrize("config,scaling,batch", [("c3", "strong", 4), ("c2", "weak", 2)])
 def test_bench_self_spawns_two_ranks(config, scaling, batch):
-    res = _run(["--gpus", "2", "--config", config])
+    res = _run(["--gpus", "2", "--config", config, "--fp-clips", "1"])
     assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["config"]["name"] == config
     assert res["config"]["global_batch"] == batch and res["steps"] == 1 and res["higher_is_better"] is True
-    assert res["value"] > 0 and res["ms_per_step"] > 0 and res["allgather_us"] > 0
-    assert res["allgather_bytes_per_rank"] == (batch * 2 // 2) * 32 * 4096 * 4
-    assert "frame-parallel x2" in res["config"]["parallelism"] and "DRY RUN" in res["data"]
+    assert res["value"] > 0 and res["ms_per_step"] > 0
+    assert "clip teams over 2 ranks" in res["config"]["parallelism"] and "DRY RUN" in res["data"]
     assert res["loss"] == res["loss"], "rank 0 owns clip 0: its loss must be a number"
-    assert res["allgather_in_step"] == (config == "c3")   # one clip per GPU (c2): the collective carries nothing and is skipped
-    assert res["rccl_ranks"] == 2
+    assert res["token_exchange_in_step"] is False    # 2 ranks, 4 (c3) or 2 (c2) clips: whole clips per rank, teams of one
+    assert res["frames_per_rank"] == [batch, batch] and res["rccl_ranks"] == 2
     if config == "c3":
         assert res["config"]["video_tokens_per_clip"] == 2 * 32 and "residual" in res["config"]["workload"]   # R clamped to the 2 frames of the dry run
+        assert res["plan"]["teams"] == [[0], [1], [0], [1]]
         assert "frame_parallel" not in res            # the c3 line IS the frame-parallel experiment
     else:
-        # the driver's `bench.py --gpus N` (no --config) must carry the north star's experiment: c3 strong scaling, rank 0 alone first, then
-        # all ranks with the all-gather inside the step, and the gathered block checked against the single-GPU encode
+        # the driver's `bench.py --gpus N` (no --config) must carry the north star's experiment: c3 strong scaling, rank 0 alone first, then all
+        # ranks as clip teams (here --fp-clips 1: ONE clip on 2 ranks = a team of two, 1 frame each, point-to-point exchange, sequence-parallel
+        # prefill), the received blocks checked against the single-GPU encode, throughput AND one-batch latency timed
         fp = res["frame_parallel"]
-        assert fp["config"] == "c3" and fp["scaling"] == "strong" and fp["allgather_in_step"] is True
+        assert fp["config"] == "c3" and fp["scaling"] == "strong" and fp["token_exchange_in_step"] is True and fp["sequence_parallel_prefill"] is True
         assert fp["ms_per_step_1gpu"] > 0 and fp["ms_per_step"] > 0 and abs(fp["speedup"] - fp["ms_per_step_1gpu"] / fp["ms_per_step"]) < 1e-2
-        assert fp["frames_per_rank"] == [4, 4] and fp["clips_per_rank"] == [2, 2] and fp["allgather_us"] > 0
-        assert fp["gathered_block_bit_identical"] is True and fp["gathered_block_max_abs_diff"] == 0.0
-        assert fp["allgather_bytes_per_rank"] == 4 * 32 * 4096 * 4
+        assert fp["latency_ms"] > 0 and abs(fp["latency_speedup"] - fp["ms_per_step_1gpu"] / fp["latency_ms"]) < 1e-2
+        assert fp["plan"]["teams"] == [[0, 1]] and fp["plan"]["frames"] == [[[0, 1], [1, 2]]]
+        assert fp["frames_per_rank"] == [1, 1] and fp["clips_per_rank"] == [1, 1] and fp["token_exchange_us"] > 0
+        assert fp["received_blocks_bit_identical"] is True and fp["received_blocks_max_abs_diff"] == 0.0
+        assert fp["token_exchange_bytes_sent_per_rank"] == [32 * 4096 * 4] * 2
 
 
 def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():
-    """N = 1 (the driver's BENCH run): the c2 line must carry the frame_parallel_projection block (c3 on one GPU, every
-    kind of rank's share at N = 2 / 4 / 8 timed alone, projected_ms = slowest share + a MODELLED all-gather), ms_per_step_blocks and the
-    telemetry key (null without a GPU)."""
+    """N = 1 (the driver's BENCH run): the c2 line must carry the frame_parallel_projection block (c3 on one GPU, every kind of rank of the
+    TeamPlan at N = 2 / 4 / 8 played alone: throughput_ms AND latency_ms from the measured shares + a modelled wire, labelled unmeasured),
+    ms_per_step_blocks and the telemetry key (null without a GPU)."""
     res = _run(["--gpus", "1"])
     assert res["n_gpus"] == 1 and res["config"]["name"] == "c2" and res["steps"] == 1
     assert res["ms_per_step_blocks"]["steps"] == [1] and len(res["ms_per_step_blocks"]["ms"]) == 1 and "telemetry" in res
     pj = res["frame_parallel_projection"]
-    assert pj["config"] == "c3" and pj["ms_per_step_1gpu"] > 0 and set(pj["n"]) == {"2", "4", "8"}
+    assert pj["config"] == "c3" and pj["ms_per_step_1gpu"] > 0 and set(pj["n"]) == {"2", "4", "8"} and "UNMEASURED" in pj["status"]
     for N, blk in pj["n"].items():
         N = int(N)
-        assert len(blk["frames_per_rank"]) == N and sum(blk["frames_per_rank"]) == 4 * 2
-        assert sum(sh["ranks_of_this_kind"] for sh in blk["shares"]) == N and all(sh["ms"] > 0 for sh in blk["shares"])
-        assert sum(sh["clips_prefilled"] * sh["ranks_of_this_kind"] for sh in blk["shares"]) == 4      # every clip prefilled exactly once
-        slow = max(sh["ms"] for sh in blk["shares"])
-        if blk["allgather_needed"]:
-            assert "modelled" in blk["allgather_model"]["assumptions"] and blk["allgather_model"]["ring_ms"] >= blk["allgather_model"]["direct_ms"] > 0
-            assert abs(blk["projected_ms"] - (slow + blk["allgather_model"]["direct_ms"])) < 2e-3
-        else:
-            assert blk["allgather_model"] is None and abs(blk["projected_ms"] - slow) < 2e-3
-        assert abs(blk["projected_speedup"] - pj["ms_per_step_1gpu"] / blk["projected_ms"]) < 2e-2
-    assert pj["n"]["4"]["allgather_needed"] is False       # one clip per rank: every rank's frame range is the clip it prefills
-    assert pj["n"]["8"]["frames_per_rank"][:4] != pj["n"]["8"]["frames_per_rank"][4:] or True
+        assert sum(sh["ranks_of_this_kind"] for sh in blk["shares"]) == N and all(sh["step_ms"] >= sh["enc_ms"] > 0 for sh in blk["shares"])
+        assert sum(sum(sh["frames"]) * sh["ranks_of_this_kind"] for sh in blk["shares"]) == 4 * 2        # every frame encoded exactly once
+        slow = max(sh["step_ms"] for sh in blk["shares"])
+        assert abs(blk["throughput_ms"] - (slow + blk["token_exchange_ms_modelled"] + blk["kv_lag_ms_modelled"])) < 2e-3
+        assert blk["latency_ms"] > 0 and abs(blk["latency_speedup"] - pj["ms_per_step_1gpu"] / blk["latency_ms"]) < 2e-2
+        assert abs(blk["throughput_speedup"] - pj["ms_per_step_1gpu"] / blk["throughput_ms"]) < 2e-2
+        teams = blk["plan"]["teams"]
+        assert (blk["token_exchange_ms_modelled"] > 0) == any(len(t) > 1 for t in teams)
+    assert pj["n"]["4"]["plan"]["teams"] == [[0], [1], [2], [3]] and pj["n"]["4"]["kv_lag_ms_modelled"] == 0      # one clip per rank: nothing on the wire
+    assert pj["n"]["8"]["plan"]["teams"] == [[0, 4], [1, 5], [2, 6], [3, 7]] and all(pj["n"]["8"]["plan"]["sp"])
+    assert any(p["sequence_parallel"] for sh in pj["n"]["8"]["shares"] for p in sh["prefill"])
 
 
 @pytest.mark.parametrize("config", ["c4", "c5"])

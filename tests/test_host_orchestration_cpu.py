@@ -174,6 +174,24 @@ def _fp_worker(rank, world, port, cfg_names, q):
                 out3 = model(samples=samples3)
             assert not model.model.stllm_model._fp_local_clips
             q.put((cfg_name + "/image_batch", rank, None, out3.logits.clone(), single3))
+            # ONE clip of 4 frames on 2 ranks: a team of two — 2 frames each, the sub-blocks exchanged point-to-point, the prefill sequence-parallel
+            # (rank 0: positions [0, s), rank 1: [s, S) with rank 0's K | V rows received per layer), the loss accumulated along the team
+            samples4, _ = make_inputs(1, 4, cfg["qformer_text_input"])
+            sm = model.model.stllm_model
+            with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+                sm.set_frame_parallel(0, 1)
+                single4 = model(samples=samples4)
+                sm.set_frame_parallel(rank, world)
+                sm._fp_keep_tokens = True
+                out4 = model(samples=samples4)
+                sm._fp_keep_tokens = False
+                blk = sm._fp_last_tokens[0].clone()
+                sm.set_frame_parallel(0, 1)
+                frames4 = samples4["image"].reshape(4, 3, 224, 224)
+                qt4 = [it.split("Human: ")[1].split(" ###")[0] for it in samples4["instruction_input"]] * 4 if cfg["qformer_text_input"] else None
+                ref_blk = torch.cat([sm._encode_frames(frames4[a:b], qt4[a:b] if qt4 else None, 4, torch.float32) for a, b in ((0, 2), (2, 4))])
+            q.put((cfg_name + "/team_sp", rank, out4.sp_rows, out4.logits.clone(), single4.logits.clone(),
+                   float(out4.loss), float(single4.loss), bool(out4.loss_complete), bool(torch.equal(blk, ref_blk))))
         del model
     dist.barrier()
     dist.destroy_process_group()
@@ -194,7 +212,7 @@ def test_frame_parallel_model_matches_single_process():
     for p in procs:
         p.start()
     res = []
-    n_results = world * (len(cfg_names) + 2)      # + the one-clip-per-rank and the image-batch case of the eva_clip_g config
+    n_results = world * (len(cfg_names) + 3)      # + the one-clip-per-rank, the image-batch and the team / sequence-parallel case of the eva_clip_g config
     while len(res) < n_results:      # a worker that died must fail the test, not hang it
         try:
             res.append(q.get(timeout=10))
@@ -205,9 +223,10 @@ def test_frame_parallel_model_matches_single_process():
         assert p.exitcode == 0
     for cfg_name in cfg_names:
         seen = []
-        for name, rank, own, logits, single in res:
-            if name != cfg_name:
+        for item in res:
+            if item[0] != cfg_name:
                 continue
+            name, rank, own, logits, single = item
             assert own == [c for c in range(3) if c % world == rank]
             seen += own
             # the sharded run pads to the longest sequence among the OWNED clips only: compare the common prefix of valid rows
@@ -222,12 +241,63 @@ def test_frame_parallel_model_matches_single_process():
     assert len(img) == world
     for name, rank, _, logits, single in img:     # every rank: the full batch, every image paired with ITS prompt and answer
         assert logits.shape == single.shape and (logits - single).abs().max() <= 5e-5, f"{name}: rank {rank}"
+    sp = sorted((r for r in res if r[0].endswith("/team_sp")), key=lambda r: r[1])
+    assert len(sp) == world
+    S = sp[0][4].shape[1]
+    assert sp[0][2][0] == 0 and sp[0][2][1] == sp[1][2][0] and sp[1][2][1] == S and sp[0][2][1] % 32 == 0     # the two position ranges tile the sequence
+    for name, rank, (s0, s1), logits, single, loss, loss1, complete, blk_same in sp:
+        assert blk_same, f"{name}: rank {rank}: the exchanged token block differs from the 1-process encode of the same frame ranges"
+        assert logits.shape[1] == s1 - s0 and (logits[0] - single[0, s0:s1]).abs().max() <= 5e-5 * single.abs().max(), f"{name}: rank {rank}"
+        assert complete == (rank == world - 1)
+        if complete:
+            assert abs(loss - loss1) <= 1e-5, (loss, loss1)
     extra = [r for r in res if r[0].endswith("/one_clip_per_rank")]
     assert len(extra) == world
     for name, rank, own, logits, single in extra:
         assert own == [rank]
         n = min(logits.shape[1], single.shape[1])
         assert (logits[0, :n] - single[rank, :n]).abs().max() <= 5e-5, name
+
+
+@pytest.mark.parametrize("world,clips,frames", [(3, 1, 4), (4, 2, 2)])
+def test_clip_teams_one_process_mailbox(world, clips, frames):
+    """The clip-team path with ONE process playing the ranks one after another (parallel.Mailbox stands in for the wire — the arrangement
+    bench.py's per-rank shares and the -m gpu test use): a team of THREE on one clip (frames 2 / 1 / 1; the K | V rows of members 0 and 1
+    reach member 2, the loss runs along the chain) and two teams of two.  Every rank's logits rows equal the unsharded run's."""
+    from stllm_amd import parallel, runtime
+    cfg = CFGS["instructblip_residual_text"]
+    model = build(cfg)
+    sm = model.model.stllm_model
+    samples, _ = make_inputs(clips, frames, True)
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        sm.set_frame_parallel(0, 1)
+        single = model(samples=samples)
+    plan = parallel.TeamPlan(clips, frames, world)
+    box = parallel.Mailbox()
+    seen = {c: [] for c in range(clips)}
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        # token exchange: a member's receive needs every peer's send -> play the ENCODE + send of all ranks first (dummy receives), then the real pass
+        pre = parallel.Mailbox(dummy=True)
+        for r in range(world):
+            sm.set_frame_parallel(r, world, mailbox=pre)
+            model(samples=samples)
+        box.box = {k: v for k, v in pre.box.items() if k[2][0] == "tok"}
+        keep = dict(box.box)
+        for r in range(world):
+            box.box.update({k: v for k, v in keep.items() if k[1] == r})
+            sm.set_frame_parallel(r, world, mailbox=box)
+            out = model(samples=samples)
+            (c,) = sm.owned_clips
+            s0, s1 = out.sp_rows
+            seen[c].append((s0, s1))
+            ref = single.logits[c, : single.logits.shape[1]]
+            n = min(s1, ref.shape[0])
+            assert (out.logits[0, : n - s0] - ref[s0:n]).abs().max() <= 5e-5 * single.logits.abs().max(), (r, c, s0, s1)
+            assert out.loss_complete == (r == plan.team[c][-1])
+    sm.set_frame_parallel(0, 1)
+    for c, rr in seen.items():
+        rr.sort()
+        assert rr[0][0] == 0 and all(rr[i][1] == rr[i + 1][0] for i in range(len(rr) - 1)), rr
 
 
 def test_chat_upload_raw_frames_on_host_graph():

@@ -238,6 +238,33 @@ def test_config5_minigpt4base_btadapter_vs_oracle():
     assert abs(out.loss.item() - ref["loss"].item()) <= 1e-3
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_sequence_parallel_prefill_matches_the_whole_prefill(mode, tol):
+    """Round 5 (stllm_amd.parallel): the members of a clip team run the decoder layers on their position ranges, K | V rows travelling forward
+    per layer.  ONE GPU plays the members one after another (parallel.Mailbox is the wire): teams of 2 and 3 over S = 580 positions (config 3's
+    prefill) — every member's hidden rows equal the whole prefill's rows (same kernels on fewer rows; tile shapes differ, so fp32 rounding, not bits)."""
+    from stllm_amd import parallel, runtime
+    from stllm_amd.models.st_llm import STLLMForCausalLM, StllmConfig
+    lm = fill(STLLMForCausalLM(StllmConfig(num_hidden_layers=3), device="cuda")).model
+    S = 580
+    emb = T("input.inputs_embeds_sp", (1, S, 4096), 0.05).cuda()
+    with runtime.use_dtype(mode):
+        whole, _ = lm.prefill(emb, None)
+        for k in (2, 3):
+            box = parallel.Mailbox()
+            edges = []
+            for j in range(k):
+                out = lm(inputs_embeds=emb, sp=dict(index=j, size=k, ranks=list(range(k)), rank=j, mailbox=box))
+                s0, s1 = out._sp_rows
+                edges.append((s0, s1))
+                ref = whole[0, s0:s1]
+                err = float((out.last_hidden_state[0] - ref).abs().max()) / float(ref.abs().max())
+                assert err <= tol, f"{mode} team of {k}, member {j} rows [{s0}, {s1}): rel err {err:.3e}"
+            assert edges == parallel.sp_row_ranges(S, k) and not box.box, "every K | V block sent was received"
+    from stllm_amd import hip
+    assert hip.gemm_workspace_ok()
+
+
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 def test_stack_entry_points_are_bit_identical_to_the_per_op_path(mode):
     """stllm_vit_blocks / stllm_llama_layers / stllm_qformer_layers (one C call per layer stack, csrc/stacks.cpp) issue exactly the launches of
