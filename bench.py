@@ -495,8 +495,11 @@ def frame_parallel_projection(args, device):
     S = int(model(samples=samples).logits.shape[1])
     per_n = {}
     try:
-        for N in (2, 4, 8):
-            sm.set_frame_parallel(0, N, mailbox=parallel.Mailbox(dummy=True))
+        for N, variant in ((2, None), (4, None), (8, None), (8, "owner_only")):
+            # variant "owner_only": the round-4 work split on the round-5 wire — the clip's owner prefills alone and encodes fewer frames (water-filled,
+            # balance "throughput"): the better PIPELINED throughput, the worse one-batch latency; reported next to the default for the trade-off
+            spk = dict(sp=False, balance="throughput") if variant else dict(sp=True, balance="latency")
+            sm.set_frame_parallel(0, N, mailbox=parallel.Mailbox(dummy=True), **spk)
             plan = sm._team_plan(B, T)
 
             def kind(r):
@@ -504,7 +507,7 @@ def frame_parallel_projection(args, device):
             meas = {}
             for k in sorted(set(kind(r) for r in range(N))):
                 r = min(q for q in range(N) if kind(q) == k)
-                sm.set_frame_parallel(r, N, mailbox=parallel.Mailbox(dummy=True))
+                sm.set_frame_parallel(r, N, mailbox=parallel.Mailbox(dummy=True), **spk)
                 enc_ms = timed(lambda: sm.encode_img(samples["image"], qtext), stepsN, 1)
                 step_ms = timed(lambda: model(samples=samples), stepsN, 1)
                 meas[k] = (enc_ms, step_ms)
@@ -517,19 +520,19 @@ def frame_parallel_projection(args, device):
             lat = 0.0
             for c in range(B):
                 enc = max(meas[kind(m)][0] for m in plan.team[c])
-                pre = max(meas[kind(m)][1] - meas[kind(m)][0] for m in (plan.team[c] if plan.sp[c] else plan.team[c][:1]))
+                pre = max(max(0.0, meas[kind(m)][1] - meas[kind(m)][0]) for m in (plan.team[c] if plan.sp[c] else plan.team[c][:1]))
                 lat = max(lat, enc + (tok_ms if len(plan.team[c]) > 1 else 0.0) + pre + (sp_lag if plan.sp[c] else 0.0))
             thr = max(v[1] for v in meas.values()) + tok_ms + sp_lag
             shares = [{"ranks_of_this_kind": sum(1 for q in range(N) if kind(q) == k), "frames": list(k[0]),
                        "prefill": [{"member": j, "team_size": kk, "sequence_parallel": bool(spf)} for j, kk, spf in k[1]],
                        "enc_ms": round(v[0], 3), "step_ms": round(v[1], 3)} for k, v in sorted(meas.items())]
-            per_n[str(N)] = {"plan": plan.describe(), "shares": shares, "token_exchange_ms_modelled": round(tok_ms, 3), "kv_lag_ms_modelled": round(sp_lag, 3),
+            per_n[str(N) + ("_" + variant if variant else "")] = {"plan": plan.describe(), "shares": shares, "token_exchange_ms_modelled": round(tok_ms, 3), "kv_lag_ms_modelled": round(sp_lag, 3),
                              "throughput_ms": round(thr, 3), "throughput_speedup": round(ms1 / thr, 3),
                              "latency_ms": round(lat, 3), "latency_speedup": round(ms1 / lat, 3),
                              "projected_ms": round(thr, 3), "projected_speedup": round(ms1 / thr, 3),
                              "sum_of_shares_over_1gpu": round(sum(meas[kind(q)][1] for q in range(N)) / ms1, 3)}
     finally:
-        sm.set_frame_parallel(0, 1)
+        sm.set_frame_parallel(0, 1, sp=True, balance="latency")
     R = mconf["residual_size"]
     res = {"config": "c3", "workload": f"BASELINE configs[2]: B={B} clips x T={T} frames, text-conditioned Q-Former, residual pooling R={R}, strong scaling",
            "status": "UNMEASURED on a multi-GPU node — measured shares of ONE GPU + a modelled wire",

@@ -70,16 +70,17 @@ def qformer_shapes(layers=12, text=True, vocab=30523, p="Qformer.bert."):
 
 
 def stllm_model_shapes(vit_depth=39, qf_layers=12, text=False, video_input=None, mvm_decode=False,
-                       vit_model="eva_clip_g", adapter_depth=3, qf_vocab=30523, p="model.stllm_model."):
+                       vit_model="eva_clip_g", adapter_depth=3, qf_vocab=30523, p="model.stllm_model.", has_qformer=True):
     """STLLMModel parameters (st_llm.py:240-250, 254, 273, 314) under the prefix set at st_llm.py:51."""
     s = {}
     s.update(vit_shapes(vit_depth, p + "visual_encoder.") if vit_model == "eva_clip_g"
              else btadapter_shapes(vit_depth, adapter_depth, p + "visual_encoder."))
     s[p + "ln_vision.weight"] = (1408,)
     s[p + "ln_vision.bias"] = (1408,)
-    s[p + "query_tokens"] = (1, 32, 768)
-    s.update(qformer_shapes(qf_layers, text, qf_vocab, p + "Qformer.bert."))
-    s[p + "llama_proj.weight"] = (4096, 768)
+    if has_qformer:
+        s[p + "query_tokens"] = (1, 32, 768)
+        s.update(qformer_shapes(qf_layers, text, qf_vocab, p + "Qformer.bert."))
+    s[p + "llama_proj.weight"] = (4096, 768 if has_qformer else 4 * 1408)   # st_llm.py:299-301, 314
     s[p + "llama_proj.bias"] = (4096,)
     if video_input == "residual":
         s.update({p + "down_proj.weight": (1024, 4096), p + "down_proj.bias": (1024,),

@@ -294,10 +294,12 @@ def qformer_forward(query_embeds: Tensor, enc: Tensor, sd: SD, p: str = "Qformer
 # =====================================================================================
 def encode_img(image: Tensor, sd: SD, p: str = "", vit_model: str = "eva_clip_g",
                text_ids: Optional[Tensor] = None, text_mask: Optional[Tensor] = None,
-               adapter_depth: int = 3) -> Tensor:
-    """STLLMModel.encode_img st_llm.py:321-377 (has_qformer=True path).
+               adapter_depth: int = 3, has_qformer: bool = True) -> Tensor:
+    """STLLMModel.encode_img st_llm.py:321-377.
     image: 5-D [B,T,3,224,224] -> [B,T,32,4096]; 4-D [T,3,224,224] (inference) -> [T,32,4096].
-    text_ids/text_mask: BERT ids already repeated per frame, [N,Lt] (st_llm.py:337-350)."""
+    text_ids/text_mask: BERT ids already repeated per frame, [N,Lt] (st_llm.py:337-350).
+    has_qformer=False (st_llm.py:369-373): no Q-Former — the 256 patch tokens (CLS dropped) are viewed as 64 rows of 4 concatenated
+    tokens, [N, 64, 5632], and projected by llama_proj(5632 -> 4096): 64 tokens per frame."""
     five = image.ndim == 5
     T = image.shape[1]
     if vit_model == "eva_clip_g":
@@ -307,6 +309,13 @@ def encode_img(image: Tensor, sd: SD, p: str = "", vit_model: str = "eva_clip_g"
         emb = btadapter_forward(image, sd, p + "visual_encoder.", adapter_depth)
     emb = ln_vision(emb, sd, p + "ln_vision")
     N = emb.shape[0]
+    if not has_qformer:
+        emb = emb[:, 1:, :]                                            # :370
+        bs, pn, hs = emb.shape
+        out = _lin(emb.reshape(bs, pn // 4, hs * 4), sd, p + "llama_proj")   # :371-373
+        if five:
+            out = out.reshape(-1, T, out.shape[1], out.shape[2])
+        return out
     q = sd[p + "query_tokens"].expand(N, -1, -1)
     att = None
     if text_ids is not None:
@@ -531,7 +540,7 @@ def mvm_loss(mask_hidden: Tensor, unmask_hidden: Tensor, mask: Tensor, img_start
 def stllm_forward(samples: dict, sd: SD, cfg: dict):
     """samples: {"image": [B,T,3,224,224], "before_ids","after_ids","answer_ids": list[list[int]],
     optional "qformer_ids"/"qformer_mask": [B,Lt], optional "mask": [B,L] bool (injected, True = dropped)}.
-    cfg: vit_model, video_input, residual_size, use_mask, mvm_decode, qformer_text_input, pad_id, bos_id, n_heads.
+    cfg: vit_model, video_input, residual_size, use_mask, mvm_decode, qformer_text_input, has_qformer, pad_id, bos_id, n_heads.
     Returns dict(logits, loss, loss_mvm, inputs_embeds, attention_mask, targets)."""
     p = "model.stllm_model."
     image = samples["image"]
@@ -540,7 +549,7 @@ def stllm_forward(samples: dict, sd: SD, cfg: dict):
     if cfg.get("qformer_text_input", False):
         tids = samples["qformer_ids"].repeat_interleave(T, dim=0)
         tmask = samples["qformer_mask"].repeat_interleave(T, dim=0)
-    emb = encode_img(image, sd, p, cfg.get("vit_model", "eva_clip_g"), tids, tmask)
+    emb = encode_img(image, sd, p, cfg.get("vit_model", "eva_clip_g"), tids, tmask, has_qformer=cfg.get("has_qformer", True))
     emb = video_pool(emb, cfg.get("video_input"), sd, p, cfg.get("residual_size", 4))
     un = None
     mask = None

@@ -64,8 +64,8 @@ class STLLMModel(Blip2Base):
                  use_grad_checkpoint=False, vit_precision="fp16", freeze_vit=True, has_qformer=True,
                  freeze_qformer=True, num_query_token=32, llama_model="", max_txt_len=32, end_sym="\n", device=None):
         super().__init__()
-        if not has_qformer or pre_encoding:
-            raise NotImplementedError("has_qformer=False / pre_encoding paths are unused by every shipped config")
+        if pre_encoding:
+            raise NotImplementedError("the pre_encoding path is unused by every shipped config")
         self.tokenizer = self.init_tokenizer(truncation_side="left")
         self.pre_encoding, self.video_input, self.use_mask = pre_encoding, video_input, use_mask
         self.mvm_decode, self.qformer_text_input, self.residual_size = mvm_decode, qformer_text_input, residual_size
@@ -79,16 +79,22 @@ class STLLMModel(Blip2Base):
         self.visual_encoder, self.ln_vision = self.init_vision_encoder(vit_model, img_size, drop_path_rate,
                                                                        use_grad_checkpoint, vit_precision, device=device)
         self.has_qformer = has_qformer
-        self.Qformer, self.query_tokens = self.init_Qformer(num_query_token, self.visual_encoder.num_features, device=device)
-        if not qformer_text_input:  # st_llm.py:277-283
-            self.Qformer.bert.embeddings.word_embeddings = None
-            self.Qformer.bert.embeddings.position_embeddings = None
-            for layer in self.Qformer.bert.encoder.layer:
-                layer.output = None
-                layer.intermediate = None
-        else:
-            self.Qformer.resize_token_embeddings(len(self.tokenizer))
-        self.Qformer.cls = None
+        if has_qformer:
+            self.Qformer, self.query_tokens = self.init_Qformer(num_query_token, self.visual_encoder.num_features, device=device)
+            if not qformer_text_input:  # st_llm.py:277-283
+                self.Qformer.bert.embeddings.word_embeddings = None
+                self.Qformer.bert.embeddings.position_embeddings = None
+                for layer in self.Qformer.bert.encoder.layer:
+                    layer.output = None
+                    layer.intermediate = None
+            else:
+                self.Qformer.resize_token_embeddings(len(self.tokenizer))
+            self.Qformer.cls = None
+            img_f_dim, self.tokens_per_frame = self.Qformer.config.hidden_size, num_query_token
+        else:   # st_llm.py:299-301, 369-373: four concatenated patch tokens per LLM token, 256 / 4 = 64 tokens per frame
+            if qformer_text_input:
+                raise ValueError("qformer_text_input needs the Q-Former (st_llm.py:337: the text goes through Qformer.bert)")
+            img_f_dim, self.tokens_per_frame = self.visual_encoder.num_features * 4, 64
         self.llama_tokenizer = IdTokenizer(pad_token_id=0, bos_token_id=1, eos_token_id=2, vocab_size=32000)
         if qformer_text_input:  # st_llm.py:306-310: '[PAD]' becomes token 32000 (the LLM's tables grow in initialize_vision_modules)
             self.llama_tokenizer.add_special_tokens({"pad_token": "[PAD]"})
@@ -96,7 +102,7 @@ class STLLMModel(Blip2Base):
                 self.llama_tokenizer.add_special_tokens({k: "</s>"})
         else:
             self.llama_tokenizer.pad_token = "$$"
-        self.llama_proj = Linear(self.Qformer.config.hidden_size, 4096, device=device)
+        self.llama_proj = Linear(img_f_dim, 4096, device=device)
         self.max_txt_len, self.end_sym = max_txt_len, end_sym
         self.embed_tokens = None  # set by STLLMLlamaModel.initialize_vision_modules (st_llm.py:54)
         self.frame_parallel = None  # (rank, world, group): see stllm_amd.parallel
@@ -200,13 +206,13 @@ class STLLMModel(Blip2Base):
                 for c, f0, f1 in enc:
                     local[c] = toks[o: o + (f1 - f0)]
                     o += f1 - f0
-            blocks = parallel.exchange_clip_tokens(local, plan, rank, group, self.fp_mailbox, device=image.device)
+            blocks = parallel.exchange_clip_tokens(local, plan, rank, group, self.fp_mailbox, token_shape=(self.tokens_per_frame, 4096), device=image.device)
             need = plan.clips_of(rank)
             self._fp_local_clips = True
             if getattr(self, "_fp_keep_tokens", False):   # bench.py / tests: the blocks as they arrived, per clip
                 self._fp_last_tokens = {c: blocks[c] for c in need}
             if not need:
-                inputs_llama = torch.zeros((0, T, 32, 4096), dtype=torch.float32, device=image.device)
+                inputs_llama = torch.zeros((0, T, self.tokens_per_frame, 4096), dtype=torch.float32, device=image.device)
             elif len(need) == 1:
                 inputs_llama = blocks[need[0]].view(1, T, -1, 4096)
             else:
@@ -232,9 +238,10 @@ class STLLMModel(Blip2Base):
             self._fp_local_clips = (not use_image) and not parallel.gather_needed(frames.shape[0], T, world, load)
             if self._fp_local_clips:   # this rank's frames ARE the clips it prefills (one clip per GPU): nothing to exchange
                 s0, e0 = parallel.frame_range(frames.shape[0], rank, world, load)
-                tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, 32, 4096), dtype=torch.float32, device=image.device)
+                tokens = enc_local(frames[s0:e0]) if e0 > s0 else torch.zeros((0, self.tokens_per_frame, 4096), dtype=torch.float32, device=image.device)
             else:
-                tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, extra=load, simulate=getattr(self, "_fp_sim_tokens", None))
+                tokens = parallel.encode_frames_parallel(enc_local, frames, rank, world, group, token_shape=(self.tokens_per_frame, 4096), extra=load,
+                                                         simulate=getattr(self, "_fp_sim_tokens", None))
             if getattr(self, "_fp_keep_tokens", False):   # bench.py's one-off check of the gathered block against a single-GPU encode
                 self._fp_last_tokens = tokens
             inputs_llama = tokens.view(-1, T, tokens.shape[1], 4096)
@@ -253,6 +260,14 @@ class STLLMModel(Blip2Base):
                 feats = self.visual_encoder.forward_flat(image)
             n = feats.shape[0] // 257
         enc16, _ = hip.layernorm(feats, self.ln_vision.weight, self.ln_vision.bias, self.ln_vision.eps, dtype=dt)
+        if not self.has_qformer:
+            if self._tape is not None:
+                raise NotImplementedError("training through the no-Q-Former projector is not implemented")
+            inputs_llama = self._project_patches(enc16, n, dt)
+            if not infer:
+                inputs_llama = inputs_llama.view(-1, T, inputs_llama.shape[1], 4096)
+            atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
+            return inputs_llama, atts_llama, use_image
         ids = tmask = None
         if self.qformer_text_input:
             ids, tmask = self._qformer_ids(text, n, T)
@@ -270,11 +285,22 @@ class STLLMModel(Blip2Base):
         atts_llama = torch.ones(inputs_llama.shape[:-1], dtype=torch.long, device=image.device)
         return inputs_llama, atts_llama, use_image
 
+    def _project_patches(self, enc16, n, dt):
+        """st_llm.py:369-373 (has_qformer=False): drop CLS, view the 256 patch tokens of a frame as 64 rows of 4 concatenated tokens and project
+        them — llama_proj(5632 -> 4096).  No copy: rows 1..256 of a frame are contiguous in the ln_vision output [n * 257, 1408], so the GEMM's A
+        operand is that buffer read through the 2-level row indexing (64 rows of 5632 per frame, frame stride 257 * 1408)."""
+        C = enc16.shape[1]
+        a = enc16.reshape(-1)[C: C + 64 * 4 * C].view(64, 4 * C)
+        w, b = self.llama_proj.packed(dt)
+        return hip.gemm(a, w, dtype=dt, bias=b, out_f32=True, M=n * 64, a_rows=(64, 257 * C)).view(n, 64, 4096)
+
     def _encode_frames(self, frames, text_per_frame, T, dt):
         """ViT -> ln_vision -> Q-Former -> projector for a flat list of frames -> [n,32,4096] fp32."""
         n = frames.shape[0]
         feats = self.visual_encoder.forward_features_flat(frames)
         enc16, _ = hip.layernorm(feats, self.ln_vision.weight, self.ln_vision.bias, self.ln_vision.eps, dtype=dt)
+        if not self.has_qformer:
+            return self._project_patches(enc16, n, dt)
         ids = tmask = None
         if self.qformer_text_input:
             tok = self.tokenizer(text_per_frame, padding="longest", truncation=True, max_length=self.max_txt_len, return_tensors="pt")
@@ -407,7 +433,7 @@ class STLLMModel(Blip2Base):
         dev = image.device
         T = image.shape[1]
         use_image = bool(T == 1 or image.dim() == 4)        # encode_img's rule (st_llm.py:326-328)
-        Lq = self.query_tokens.shape[1]
+        Lq = self.tokens_per_frame
         if use_image:
             L = Lq
         elif self.video_input == "all":

@@ -47,7 +47,13 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         return out
     if M is None:
         M = a.shape[0]
-    A = a[_rows(a, M, a_rows)].float()
+    if a_rows is None:
+        A = a[:M].float()
+    else:   # (rows_per_batch, batch_stride in elements): the stride need not be a whole number of rows (the no-Q-Former projector reads 64 rows of
+        # 5632 behind the CLS row of every 257 x 1408 frame block) -> a strided view of the storage, as the kernel's byte addressing sees it
+        rpb, bs = a_rows
+        nb = (M + rpb - 1) // rpb
+        A = torch.as_strided(a, (nb, rpb, a.shape[-1]), (bs, a.stride(-2), 1), a.storage_offset()).reshape(nb * rpb, a.shape[-1])[:M].float()
     acc = A @ wf.t()
     if bias is not None:
         acc = acc + bias

@@ -261,6 +261,14 @@ def fx_stllm_minigpt4():
                                     vit_precision="fp32"), Tn=4)
 
 
+def fx_stllm_no_qformer():
+    """st_llm.py:299-301, 369-373: has_qformer=False — 4 concatenated patch tokens per LLM token through llama_proj(5632 -> 4096), 64 tokens per
+    frame; 'mean' pooling over T = 2 frames (no shipped yaml sets it: the branch is pinned here so that the product's implementation has a reference)."""
+    fx_stllm("stllm_no_qformer", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="", video_input="mean",
+                                      use_mask=False, mvm_decode=False, qformer_text_input=False, has_qformer=False,
+                                      max_txt_len=32, end_sym=" 2", vit_precision="fp32"), Tn=2)
+
+
 def fx_stllm_instructblip():
     fx_stllm("stllm_instructblip", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32,
                                         llama_model="", video_input="residual", residual_size=4,
@@ -570,7 +578,7 @@ def fx_full(tag):
 
 
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
-           stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip,
+           stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip, stllm_no_qformer=fx_stllm_no_qformer,
            stllm_flagship=fx_stllm_flagship, btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward, pos_embed=fx_pos_embed)
 SLOW = dict(c1_full=fx_c1_full, c2_full=fx_c2_full, c3_full=lambda: fx_full("c3"), c4_full=lambda: fx_full("c4"), c5_full=lambda: fx_full("c5"))
 

@@ -67,6 +67,8 @@ CFGS = {
                                        max_txt_len=32, end_sym=" 2"),
     "mean_pooling": dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="mean", use_mask=False,
                          mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2"),
+    "no_qformer_mean": dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="mean", use_mask=False, mvm_decode=False,
+                            qformer_text_input=False, has_qformer=False, max_txt_len=32, end_sym=" 2"),
     "btadapter": dict(vit_model="eva_btadapter_g", image_size=224, num_query_token=32, video_input="all", use_mask=False,
                       mvm_decode=False, qformer_text_input=False, max_txt_len=32, end_sym=" 2"),
 }
@@ -86,7 +88,7 @@ def test_host_graph_matches_oracle(name):
         mask = torch.from_numpy(O.random_masking_generator(4 * 32, 0.5, 2))
         samples["mask"], osamples["mask"] = mask, mask
     sd = sd_from({**shapes.stllm_model_shapes(vit_depth, 2, text, cfg["video_input"], cfg["mvm_decode"],
-                                              vit_model=cfg["vit_model"], qf_vocab=32000), **shapes.llama_shapes(1)})
+                                              vit_model=cfg["vit_model"], qf_vocab=32000, has_qformer=cfg.get("has_qformer", True)), **shapes.llama_shapes(1)})
     ref = O.stllm_forward(osamples, sd, dict(cfg, pad_id=0, bos_id=1))
     with _cpu_backend.installed(), runtime.use_dtype("fp32"):
         out = model(samples=samples)

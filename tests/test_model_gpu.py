@@ -118,7 +118,10 @@ E2E = [("stllm_minigpt4", dict(vit_model="eva_clip_g", image_size=224, num_query
        # pooling + mask over the pooled R*32 block + MVM whose slices start at img_start = 0 (st_llm.py:71, 463-493)
        ("stllm_flagship", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="residual",
                                residual_size=4, use_mask=True, mvm_decode=True, qformer_text_input=True,
-                               max_txt_len=32, end_sym=" 2"), 8, True)]
+                               max_txt_len=32, end_sym=" 2"), 8, True),
+       # st_llm.py:299-301, 369-373 (has_qformer=False): 4 concatenated patch tokens per LLM token, llama_proj(5632 -> 4096), 64 tokens per frame
+       ("stllm_no_qformer", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="mean", use_mask=False, mvm_decode=False,
+                                 qformer_text_input=False, has_qformer=False, max_txt_len=32, end_sym=" 2"), 2, False)]
 
 
 @pytest.mark.parametrize("mode,tol", MODES)

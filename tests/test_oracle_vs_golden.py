@@ -114,8 +114,8 @@ def test_btadapter():
 
 def _e2e(name, cfg, Tn, text):
     g = golden(name)
-    sdshape = {**shapes.stllm_model_shapes(2, 2, text, cfg["video_input"], cfg.get("mvm_decode", False), qf_vocab=32000),
-               **shapes.llama_shapes(2)}
+    sdshape = {**shapes.stllm_model_shapes(2, 2, text, cfg["video_input"], cfg.get("mvm_decode", False), qf_vocab=32000,
+                                           has_qformer=cfg.get("has_qformer", True)), **shapes.llama_shapes(2)}
     sd = sd_from(sdshape)
     samples = {"image": T("input.video", (2, Tn, 3, 224, 224)), "before_ids": unragged(g["before"]),
                "after_ids": unragged(g["after"]), "answer_ids": unragged(g["answer"])}
@@ -156,6 +156,13 @@ def test_stllm_minigpt4_style():
 
 def test_stllm_instructblip_style():
     _e2e("stllm_instructblip", CFG_INSTRUCTBLIP, 8, True)
+
+
+def test_stllm_without_qformer():
+    """st_llm.py:299-301, 369-373 (has_qformer=False): CLS dropped, 4 patch tokens concatenated per LLM token, llama_proj(5632 -> 4096) — the
+    oracle's branch against the reference's own forward."""
+    _e2e("stllm_no_qformer", dict(vit_model="eva_clip_g", video_input="mean", use_mask=False, mvm_decode=False, qformer_text_input=False,
+                                  has_qformer=False), 2, False)
 
 
 CFG_FLAGSHIP = dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=True, mvm_decode=True, qformer_text_input=True)
