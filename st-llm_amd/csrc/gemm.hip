@@ -37,7 +37,7 @@ template <int BM, int BN> struct Tile {
   // Ring depth.  The 64 x 64 tile serves the small problems (Q-Former: M = 512 rows, K = 768 / 3072): a K panel of it is ~200 cycles of
   // matrix work per wave against a ~1000-cycle L2 round trip, so with two stages ("wait for everything, barrier, request the next panel")
   // the loop ran at one L2 latency per panel: 0.55 us x 12 .. 48 panels.  Four stages (16 KiB each) keep three panels in flight behind a
-  // counted wait (round 4).  The 128-row tiles stay at two (32-48 KiB per stage, two workgroups per CU).
+  // counted wait (round 4; 4 x 16 KiB + pad = 65 KiB: two workgroups per CU instead of four).  The 128-row tiles stay at two stages (32-48 KiB per stage, two workgroups per CU).
   static constexpr int kStages = (BM == 64 && BN == 64) ? STLLM_GEMM_RING64 : 2;
   static constexpr int kPfScratch = 1024;                   // landing pad: the L2-prefetch wave's LDS-DMA / the pieces issued past the end of the panel stream
   static constexpr int kLdsBytes = kStages * kStageBytes + kPfScratch;
@@ -910,7 +910,10 @@ int dispatch_store(const GemmParams& p, hipStream_t stream) {
 static float old_kernels_estimate_us(const GemmParams& p) {
   const int nk = p.K / 64;
   const int64_t t128 = (int64_t)((p.M + 127) / 128) * (p.N / 128);
-  if (t128 < 192) {   // 64x64 tiles, 4 workgroups per CU.  Round 4 re-calibration (profiles/r04_gemm64_ring4_harness.log, r04_gemm_vs_vendor.log): 6.9-8.4 us at
+  if (t128 < 192) {   // 64x64 tiles: with the 4-stage ring (65 KiB of LDS per workgroup) TWO workgroups are resident per CU (hipOccupancy: launch<>() asks), not the
+    // four of the 2-stage ring — up to 512 tiles run at once.  The per-256-tiles factor below is an EMPIRICAL fit of the measured launches (one "round" = the tiles
+    // one workgroup per CU covers: the second resident workgroup shares its CU's LDS fill path and roughly doubles the unit time), not a residency count.
+    // Round 4 re-calibration (profiles/r04_gemm64_ring4_harness.log, r04_gemm_vs_vendor.log): 6.9-8.4 us at
     // 12 K units, 17.7 at 48 (<= 256 tiles: one tile per CU slot), 54-68 us for the 576 tiles x 64 units of the Llama o_proj shape — the old
     // 5 + 0.55 nk over-estimated the short-K / few-tile case by 13 us and sent the Q-Former's 512 x 768 x 3072 residual GEMM to the phased
     // kernel's K-split (27.8 us, 12 launches per step) although this kernel runs it in 18-19

@@ -171,6 +171,11 @@ int stllm_gemm_bf16x3(const stllm_gemm_args* a, void* stream_) {
   STLLM_CHECK_ARG(need == 0 || (a->split_ws && aligned16(a->split_ws) && a->split_ws_bytes >= need),
                   "stllm_gemm(BF16X3): split_ws of %lld bytes needed (stllm_gemm_split_ws_bytes), %lld given", (long long)need, (long long)a->split_ws_bytes);
   STLLM_CHECK_ARG(a->epilogue != STLLM_EPI_SWIGLU || a->N % 64 == 0, "stllm_gemm(BF16X3, SWIGLU): N %% 64");
+  // the inner GEMM runs as a plain STORE, so the checks of the epilogue that the post pass applies have to be repeated here, before anything is launched
+  // (a C caller with rope_seq = 0 or NULL tables got a device fault out of post_rows_kernel<2>, a bad `act` silently ran as ReLU)
+  STLLM_CHECK_ARG(a->epilogue != STLLM_EPI_ROPE || (a->aux0 && a->aux1 && a->rope_seq > 0 && a->rope_cols % 128 == 0),
+                  "stllm_gemm(BF16X3, ROPE): need cos/sin tables, rope_seq, rope_cols%%128==0");
+  STLLM_CHECK_ARG(a->act == STLLM_ACT_NONE || a->act == STLLM_ACT_GELU || a->act == STLLM_ACT_RELU, "stllm_gemm(BF16X3): bad act %d", a->act);
   if (out_split) {   // (checked before anything is launched)
     const int n_out = a->epilogue == STLLM_EPI_SWIGLU ? a->N / 2 : a->N;
     STLLM_CHECK_ARG(a->ldo >= 3 * (int64_t)n_out && a->ldo % 4 == 0 && a->o_batch_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a->out) & 7) == 0,

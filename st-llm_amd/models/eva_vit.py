@@ -160,6 +160,10 @@ class VisionTransformer(nn.Module):
         separate HIP streams: every launch is a persistent grid that ends with a partially filled last round of tiles, and
         kernels of one stream serialise — a second independent stream fills those tails (same kernels, same numerics:
         rows of different frames never interact)."""
+        with runtime.vit_scope():     # the "mixed" verify mode runs the ViT in its own numerics mode (runtime.py)
+            return self._forward_features_flat(x)
+
+    def _forward_features_flat(self, x):
         dt = runtime.compute_dtype()
         pk = self.pack(dt)
         N = x.shape[0]

@@ -8,6 +8,9 @@
              matrix-core products of split operands (x = hi + lo; stllm_hip.h STLLM_BF16X3): the fp32 accuracy class at ~3x the
              bf16 GEMM time instead of 16x.  compute_dtype() is torch.float32 in this mode; gemm_split() tells the packers to
              store the weights split.
+  "mixed"  — (round 5) "bf16x3" everywhere EXCEPT the ViT blocks, which run in "fp16": the per-stage error ladder (profiles/r04_parity_ladder.log)
+             shows the ViT is the stage whose fp16 error stays under the bar (9.5e-3 alone; the Q-Former's is 1.3e-2, Llama's 2.3e-2), and it is
+             45 % of the GEMM time — the step costs 1.9x the bf16 step instead of 2.8x.  The visual encoder enters `vit_scope()` for its forward.
 """
 import contextlib
 
@@ -15,15 +18,33 @@ import torch
 
 from .hip import torch_dtype
 
-_state = {"dtype": torch.bfloat16, "split": False}
+_state = {"dtype": torch.bfloat16, "split": False, "vit": None}
 SPLIT_NAMES = ("bf16x3", "split")
+MIXED_VIT = "fp16"   # the ViT's mode inside "mixed"
 
 
 def set_compute_dtype(d):
-    if isinstance(d, str) and d in SPLIT_NAMES:
-        _state.update(dtype=torch.float32, split=True)
+    if isinstance(d, str) and d == "mixed":
+        _state.update(dtype=torch.float32, split=True, vit=MIXED_VIT)
+    elif isinstance(d, str) and d in SPLIT_NAMES:
+        _state.update(dtype=torch.float32, split=True, vit=None)
     else:
-        _state.update(dtype=torch_dtype(d), split=False)
+        _state.update(dtype=torch_dtype(d), split=False, vit=None)
+
+
+@contextlib.contextmanager
+def vit_scope():
+    """the numerics mode of the visual encoder's blocks: the process-wide mode, or — in "mixed" — the ViT's own"""
+    v = _state["vit"]
+    if v is None:
+        yield
+        return
+    old = dict(_state)
+    set_compute_dtype(v)
+    try:
+        yield
+    finally:
+        _state.update(old)
 
 
 def compute_dtype():
@@ -37,7 +58,7 @@ def gemm_split():
 
 def mode_name():
     if _state["split"]:
-        return "bf16x3"
+        return "mixed" if _state["vit"] else "bf16x3"
     return {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "fp32"}[_state["dtype"]]
 
 

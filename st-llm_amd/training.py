@@ -211,6 +211,10 @@ def loss_and_grads(model, samples, freeze_btadapter=False, drop_path=None, sink=
     train_adapter = sm.vit_model != "eva_clip_g" and not freeze_btadapter
     if sm.frame_parallel is not None:
         raise NotImplementedError("training is data-parallel (one micro-batch per rank); frame-parallel is the inference path")
+    if runtime.gemm_split():
+        # compute_dtype() is fp32 there but the packed weights are split bf16 [N, 3 K]: the backward's transposes / GEMMs would see a "weight" of the
+        # wrong width.  The split mode is an inference verify mode; train in bf16 / fp16 / fp32.
+        raise NotImplementedError('training does not run in the "bf16x3" split mode: use runtime.set_compute_dtype("bf16" | "fp16" | "fp32")')
     dt = runtime.compute_dtype()
     cfg = lm.config
     D = cfg.hidden_size

@@ -274,3 +274,20 @@ def test_synth_host_generator_is_bit_identical_to_the_torch_recipe():
             assert torch.equal(a, b), (n, std, mean)
     finally:
         synth._CACHE = saved
+
+
+def test_mixed_numerics_mode_scopes_the_vit_only():
+    """runtime "mixed" (round 5): the split verify mode with the ViT blocks in fp16 — vit_scope() switches the mode for the visual encoder's
+    forward and restores it, every other mode leaves vit_scope() a no-op"""
+    import torch
+    from stllm_amd import runtime
+    with runtime.use_dtype("mixed"):
+        assert runtime.mode_name() == "mixed" and runtime.compute_dtype() == torch.float32 and runtime.gemm_split()
+        with runtime.vit_scope():
+            assert runtime.mode_name() == "fp16" and runtime.compute_dtype() == torch.float16 and not runtime.gemm_split()
+        assert runtime.mode_name() == "mixed" and runtime.gemm_split()
+    for m in ("bf16", "fp16", "fp32", "bf16x3"):
+        with runtime.use_dtype(m):
+            with runtime.vit_scope():
+                assert runtime.mode_name() == m
+    assert runtime.mode_name() == "bf16"

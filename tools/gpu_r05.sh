@@ -1,7 +1,10 @@
 # round-5 device script (rewritten per call; the invocations worth keeping are listed in profiles/README.md)
-O=gpurun_out/r05d; mkdir -p $O
-python tools/gemm_bench.py --only llm_qkv,llm_o,llm_gu,llm_down,lm_head --rows 8224,288 --audit > $O/audit_288.log 2>&1
-python tools/gemm_bench.py --only llm_qkv,llm_o,llm_gu,llm_down,lm_head --rows 8224,292 --audit > $O/audit_292.log 2>&1
-python tools/gemm_bench.py --only llm_qkv,llm_o,llm_gu,llm_down,lm_head --rows 8224,384 --audit > $O/audit_384.log 2>&1
-python tools/gemm_bench.py --only llm_qkv,llm_o,llm_gu,llm_down,lm_head --rows 8224,192 --audit > $O/audit_192.log 2>&1
-grep -h "^llm\|^lm_head\|<--" $O/audit_*.log
+O=$GRAFT_REPO_ROOT/gpurun_out/r05e; mkdir -p $O
+export TMPDIR=/tmp; cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $GRAFT_REPO_ROOT/bench.py --dtype bf16x3 --steps 4 --warmup 2 --no-extra-legs --no-projection --no-cpu-baseline --no-roofline > $O/bench_x3_under_rocprof.json 2> $O/prof.err
+cd $GRAFT_REPO_ROOT
+S=$(ls $O/prof/*/*kernel_stats.csv | head -1)
+python tools/prof_summary.py $S --div 6 --top 40 --title "rocprofv3 --kernel-trace --stats of bench.py --dtype bf16x3 --steps 4 --warmup 2 (round 5 start)" > $O/x3_kernel_stats.md
+cp $S $O/x3_kernel_stats.csv; rm -rf $O/prof
+head -40 $O/x3_kernel_stats.md | cut -c1-200
+python -m pytest tests/test_model_gpu.py -x -q -k "no_qformer" 2>&1 | tail -3
