@@ -143,9 +143,20 @@ def cpu_baseline(T, S, budget_s=25.0):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import shapes
     import stllm_oracle as O
-    cores = min(os.cpu_count() or 1, 64)   # more threads than this only adds fork/join overhead at these sizes
-    torch.set_num_threads(cores)
     rnd = lambda shp: {k: torch.randn(v) * 0.02 for k, v in shp.items()}
+    # thread count: probed, not assumed (64 threads ran a frame SLOWER than the build container's 8 vCPUs — oversubscription).
+    # A small ViT slice (4 frames x 2 blocks) at 8 / 16 / 32 / 64 / all hardware threads; the sample below runs at the fastest, both are reported.
+    ncpu = os.cpu_count() or 1
+    probe = {}
+    with torch.no_grad():
+        sdp = rnd(shapes.vit_shapes(2, "v."))
+        frp = torch.randn(4, 3, 224, 224)
+        for n in sorted({c for c in (8, 16, 32, 64, 96, ncpu) if c <= ncpu} or {1}):
+            torch.set_num_threads(n)
+            O.vit_forward(frp[:1], sdp, "v.")
+            t0 = time.perf_counter(); O.vit_forward(frp, sdp, "v."); probe[n] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
+    torch.set_num_threads(cores)
     NF, VB, QL, LL = 16, 8, 12, 8    # sample: 16 frames x 8/39 ViT blocks, 16 frames x 12/12 Q-Former layers, 8/32 Llama layers (~10-20 s of CPU work)
     with torch.no_grad():
         sd = rnd(shapes.vit_shapes(VB, "v."))
@@ -165,7 +176,8 @@ def cpu_baseline(T, S, budget_s=25.0):
         t0 = time.perf_counter(); O.lm_logits(h, sd); t_head = time.perf_counter() - t0
     clip_s = T * (vit_per_frame + qf_per_frame) + 32 * t_l1 + t_head
     return {"value": round(T * 32 / clip_s, 3), "unit": "video-tokens/s", "cores": cores, "kind": "port",
-            "dtype": "f32",
+            "dtype": "f32", "host_threads_available": ncpu,
+            "thread_probe_s": {str(n): round(t, 3) for n, t in sorted(probe.items())},   # ViT 4 frames x 2 blocks at each thread count: `cores` is the fastest
             "sample": f"oracle on CPU fp32, {cores} threads: ViT {NF} frames x {VB}/39 blocks ({t_vit2:.2f}s), Q-Former {NF} frames x "
                       f"{QL}/12 layers ({t_qf:.2f}s), Llama {LL}/32 layers at S={S} ({t_l1 * LL:.2f}s) + lm_head ({t_head:.2f}s); "
                       f"extrapolated linearly to T={T}, 39/12/32 layers => {clip_s:.1f} s/clip"}
@@ -495,10 +507,11 @@ def frame_parallel_projection(args, device):
     S = int(model(samples=samples).logits.shape[1])
     per_n = {}
     try:
-        for N, variant in ((2, None), (4, None), (8, None), (8, "owner_only")):
+        for N, variant in ((2, None), (4, None), (8, None), (8, "owner_only"), (8, "owner_only_latency")):
             # variant "owner_only": the round-4 work split on the round-5 wire — the clip's owner prefills alone and encodes fewer frames (water-filled,
-            # balance "throughput"): the better PIPELINED throughput, the worse one-batch latency; reported next to the default for the trade-off
-            spk = dict(sp=False, balance="throughput") if variant else dict(sp=True, balance="latency")
+            # balance "throughput"): the better PIPELINED throughput, the worse one-batch latency; "owner_only_latency": owner-only prefill with equal
+            # frame shares.  Both reported next to the default (sequence-parallel prefill inside the team) for the trade-off.
+            spk = dict(sp=False, balance="throughput" if variant == "owner_only" else "latency") if variant else dict(sp=True, balance="latency")
             sm.set_frame_parallel(0, N, mailbox=parallel.Mailbox(dummy=True), **spk)
             plan = sm._team_plan(B, T)
 

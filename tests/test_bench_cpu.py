@@ -57,7 +57,7 @@ def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():
     assert res["n_gpus"] == 1 and res["config"]["name"] == "c2" and res["steps"] == 1
     assert res["ms_per_step_blocks"]["steps"] == [1] and len(res["ms_per_step_blocks"]["ms"]) == 1 and "telemetry" in res
     pj = res["frame_parallel_projection"]
-    assert pj["config"] == "c3" and pj["ms_per_step_1gpu"] > 0 and set(pj["n"]) == {"2", "4", "8", "8_owner_only"} and "UNMEASURED" in pj["status"]
+    assert pj["config"] == "c3" and pj["ms_per_step_1gpu"] > 0 and set(pj["n"]) == {"2", "4", "8", "8_owner_only", "8_owner_only_latency"} and "UNMEASURED" in pj["status"]
     for N, blk in pj["n"].items():
         N = int(N.split("_")[0])
         assert sum(sh["ranks_of_this_kind"] for sh in blk["shares"]) == N and all(sh["step_ms"] > 0 and sh["enc_ms"] > 0 for sh in blk["shares"])
