@@ -544,10 +544,32 @@ def frame_parallel_projection(args, device):
                              "latency_ms": round(lat, 3), "latency_speedup": round(ms1 / lat, 3),
                              "projected_ms": round(thr, 3), "projected_speedup": round(ms1 / thr, 3),
                              "sum_of_shares_over_1gpu": round(sum(meas[kind(q)][1] for q in range(N)) / ms1, 3)}
+        # ---- full-size numerics of the sequence-parallel path ON THIS GPU: the two members of clip 0's team at N = 8 played one after another through
+        # a real mailbox (token sub-blocks both ways, K | V rows and the loss forward) -> their logits rows against the 1-GPU run's rows of clip 0
+        sp_check = None
+        plan8 = parallel.TeamPlan(B, T, 8)
+        if plan8.sp[0]:
+            sm.set_frame_parallel(0, 1)
+            ref = model(samples=samples)
+            ref_lg, ref_loss = ref.logits[0].float(), None
+            outs = parallel.play_ranks(sm, lambda: model(samples=samples), plan8.team[0], 8, sp=True, balance="latency")
+            diffs, agree, rows = [], [], []
+            for r in plan8.team[0]:
+                s0, s1 = outs[r].sp_rows
+                lg = outs[r].logits[0].float()
+                n = min(s1, ref_lg.shape[0]) - s0
+                diffs.append(float((lg[:n] - ref_lg[s0:s0 + n]).abs().max().item()))
+                agree.append(float((lg[:n].argmax(-1) == ref_lg[s0:s0 + n].argmax(-1)).float().mean().item()))
+                rows.append([s0, s1])
+            sp_check = {"ranks": plan8.team[0], "rows": rows, "logits_max_abs_diff_vs_1gpu": [round(d, 6) for d in diffs],
+                        "top1_agreement_vs_1gpu": [round(a, 4) for a in agree], "logits_abs_max": round(float(ref_lg.abs().max().item()), 3), "dtype": args.dtype,
+                        "note": "same kernels on fewer rows pick other tiles / K-splits: differences are the timed dtype's rounding, not a different computation "
+                                "(fp32 mode: 2e-4 relative, tests/test_model_gpu.py::test_sequence_parallel_prefill_matches_the_whole_prefill)"}
     finally:
         sm.set_frame_parallel(0, 1, sp=True, balance="latency")
     R = mconf["residual_size"]
     res = {"config": "c3", "workload": f"BASELINE configs[2]: B={B} clips x T={T} frames, text-conditioned Q-Former, residual pooling R={R}, strong scaling",
+           "sequence_parallel_check": sp_check,
            "status": "UNMEASURED on a multi-GPU node — measured shares of ONE GPU + a modelled wire",
            "method": "measured on ONE GPU: the whole batch, then each kind of rank of the TeamPlan alone (its frames' encode; its share of its clip's prefill, "
                      "sequence-parallel inside the clip's team; receives are no-ops); throughput_ms = slowest rank's step + exchange, latency_ms = critical path of one batch",

@@ -171,6 +171,25 @@ class Mailbox:
         return out
 
 
+def play_ranks(sm, step, ranks, world, **plan_options):
+    """ONE process plays `ranks` of a `world`-rank job one after another and returns {rank: step()'s result}: `sm` is the STLLMModel whose
+    set_frame_parallel selects the rank, `step` runs one forward.  The token exchange of a team is bidirectional, so the ranks are played twice:
+    a first pass with a dummy mailbox collects every rank's token sub-blocks, the second pass delivers them and lets the K | V rows and the loss
+    travel forward through the real mailbox (ranks in ascending order: a member only ever needs what EARLIER members of its team produced).
+    Tests and bench.py's full-size check of the sequence-parallel prefill on one GPU use this."""
+    pre = Mailbox(dummy=True)
+    for r in ranks:
+        sm.set_frame_parallel(r, world, mailbox=pre, **plan_options)
+        step()
+    tokens = {k: v for k, v in pre.box.items() if k[2][0] == "tok"}
+    box, outs = Mailbox(), {}
+    for r in sorted(ranks):
+        box.box.update({k: v for k, v in tokens.items() if k[1] == r})
+        sm.set_frame_parallel(r, world, mailbox=box, **plan_options)
+        outs[r] = step()
+    return outs
+
+
 def p2p_exchange(sends, recvs, rank, group=None, mailbox=None):
     """sends: [(tensor, dst rank, tag)], recvs: [(out tensor, src rank, tag)] -> list of work handles to wait on (empty for the mailbox, which
     completes at once).  One batched isend / irecv: RCCL runs the pairs concurrently, each over the direct xGMI link of its two ranks."""

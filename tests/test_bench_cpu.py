@@ -71,6 +71,8 @@ def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():
     assert pj["n"]["4"]["plan"]["teams"] == [[0], [1], [2], [3]] and pj["n"]["4"]["kv_lag_ms_modelled"] == 0      # one clip per rank: nothing on the wire
     assert pj["n"]["8"]["plan"]["teams"] == [[0, 4], [1, 5], [2, 6], [3, 7]] and all(pj["n"]["8"]["plan"]["sp"])
     assert any(p["sequence_parallel"] for sh in pj["n"]["8"]["shares"] for p in sh["prefill"])
+    chk = pj["sequence_parallel_check"]      # the two members of clip 0's team at N = 8, played on this process: their rows tile the sequence and equal the 1-process logits
+    assert chk["ranks"] == [0, 4] and chk["rows"][0][0] == 0 and chk["rows"][0][1] == chk["rows"][1][0] and max(chk["logits_max_abs_diff_vs_1gpu"]) <= 1e-3
     oo = pj["n"]["8_owner_only"]      # the owner prefills alone and encodes fewer frames: helpers have no prefill share
     assert not any(oo["plan"]["sp"]) and sorted(len(sh["prefill"]) for sh in oo["shares"]) == [0, 1] and oo["kv_lag_ms_modelled"] == 0
 

@@ -275,27 +275,17 @@ def test_clip_teams_one_process_mailbox(world, clips, frames):
         sm.set_frame_parallel(0, 1)
         single = model(samples=samples)
     plan = parallel.TeamPlan(clips, frames, world)
-    box = parallel.Mailbox()
     seen = {c: [] for c in range(clips)}
     with _cpu_backend.installed(), runtime.use_dtype("fp32"):
-        # token exchange: a member's receive needs every peer's send -> play the ENCODE + send of all ranks first (dummy receives), then the real pass
-        pre = parallel.Mailbox(dummy=True)
-        for r in range(world):
-            sm.set_frame_parallel(r, world, mailbox=pre)
-            model(samples=samples)
-        box.box = {k: v for k, v in pre.box.items() if k[2][0] == "tok"}
-        keep = dict(box.box)
-        for r in range(world):
-            box.box.update({k: v for k, v in keep.items() if k[1] == r})
-            sm.set_frame_parallel(r, world, mailbox=box)
-            out = model(samples=samples)
-            (c,) = sm.owned_clips
-            s0, s1 = out.sp_rows
-            seen[c].append((s0, s1))
-            ref = single.logits[c, : single.logits.shape[1]]
-            n = min(s1, ref.shape[0])
-            assert (out.logits[0, : n - s0] - ref[s0:n]).abs().max() <= 5e-5 * single.logits.abs().max(), (r, c, s0, s1)
-            assert out.loss_complete == (r == plan.team[c][-1])
+        outs = parallel.play_ranks(sm, lambda: (model(samples=samples), list(sm.owned_clips)), range(world), world)
+    for r, (out, own) in outs.items():
+        (c,) = own
+        s0, s1 = out.sp_rows
+        seen[c].append((s0, s1))
+        ref = single.logits[c, : single.logits.shape[1]]
+        n = min(s1, ref.shape[0])
+        assert (out.logits[0, : n - s0] - ref[s0:n]).abs().max() <= 5e-5 * single.logits.abs().max(), (r, c, s0, s1)
+        assert out.loss_complete == (r == plan.team[c][-1])
     sm.set_frame_parallel(0, 1)
     for c, rr in seen.items():
         rr.sort()
