@@ -495,13 +495,13 @@ class STLLMModel(Blip2Base):
         # ---- device work: encode -> pooling -> ONE gather per sequence block ----------------------------------------------
         img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
         assert use_image_enc == use_image
+        if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
+            return None
         if not use_image:
             img_embeds = self.pool_video(img_embeds)
         elif img_embeds.dim() == 3:
             img_embeds = img_embeds.unsqueeze(1)
         if own is not None:
-            if not own:
-                return None
             if not getattr(self, "_fp_local_clips", False):   # (skipped all-gather: img_embeds holds exactly the owned clips already)
                 img_embeds = img_embeds[own].contiguous()
         assert tuple(img_embeds.shape[:3]) == (B, 1, L), (tuple(img_embeds.shape), B, L)

@@ -139,6 +139,7 @@ def gather_rows(src_a, idx_a, *, src_b=None, add=None, idx_add=None, out=None, s
 
 
 def mean_t(x):
+    assert x.shape[0] > 0 and x.shape[1] > 0, "stllm_mean_t: empty batch (the device binding indexes x[0, 0])"
     return x.float().mean(dim=1)
 
 
