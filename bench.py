@@ -380,6 +380,34 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
            "frames_per_rank": [sum(f1 - f0 for _, f0, f1 in plan.encodes(r)) for r in range(world)],
            "clips_per_rank": [len(plan.clips_of(r)) for r in range(world)],
            "received_blocks_bit_identical": ident, "received_blocks_max_abs_diff": ident_err}
+    # ---- the round-4 work split on the same wire, for the trade-off (only where teams exist): the clip's owner prefills alone and encodes fewer
+    # frames (water-filled): the better pipelined throughput, the worse one-batch latency
+    if plan.exchange_needed() and any(plan.sp):
+        sm.set_frame_parallel(rank, world, sp=False, balance="throughput")
+        plan2 = sm._team_plan(B, T)
+        for _ in range(1 if dry else 3):
+            model(samples=samples)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(stepsN):
+            model(samples=samples)
+        sync()
+        dt2 = time.perf_counter() - t0
+        lat2 = 0.0
+        for _ in range(stepsL):
+            sync()
+            t1 = time.perf_counter()
+            model(samples=samples)
+            sync()
+            lat2 += time.perf_counter() - t1
+        t = torch.tensor([dt2, lat2], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms2, msL2 = float(t[0].item()) / stepsN * 1e3, float(t[1].item()) / stepsL * 1e3
+        res["owner_only_throughput_plan"] = {"ms_per_step": round(ms2, 3), "speedup": round(ms1 / ms2, 3) if ms2 > 0 else None, "latency_ms": round(msL2, 3),
+                                             "latency_speedup": round(ms1 / msL2, 3) if msL2 > 0 else None,
+                                             "frames_per_rank": [sum(f1 - f0 for _, f0, f1 in plan2.encodes(r)) for r in range(world)],
+                                             "clips_per_rank": [len(plan2.clips_of(r)) for r in range(world)]}
+        sm.set_frame_parallel(rank, world, sp=True, balance="latency")
     del model
     return res
 

@@ -47,6 +47,8 @@ def test_bench_self_spawns_two_ranks(config, scaling, batch):
         assert fp["frames_per_rank"] == [1, 1] and fp["clips_per_rank"] == [1, 1] and fp["token_exchange_us"] > 0
         assert fp["received_blocks_bit_identical"] is True and fp["received_blocks_max_abs_diff"] == 0.0
         assert fp["token_exchange_bytes_sent_per_rank"] == [32 * 4096 * 4] * 2
+        oo = fp["owner_only_throughput_plan"]     # the same batch with the owner prefilling alone (helpers return before pooling): timed next to the default
+        assert oo["ms_per_step"] > 0 and oo["latency_ms"] > 0 and oo["clips_per_rank"] == [1, 0] and sum(oo["frames_per_rank"]) == 2
 
 
 def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():
