@@ -145,7 +145,7 @@ int stllm_gemm_workspace_status(const void* workspace, void* stream);
  * tile_rows x 256; the s workgroups of a remainder tile sit on one XCD (s <= 32, 8 * cap >= r, cap = 32 / s). */
 int stllm_gemm_plan(int M, int N, int K, int heavy, int tile_rows, int* plan5);
 /* The same for the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc): shape = 32 (192 x 128 tile) | 42 (256 x 128) | 34 (192 x 256) |
- * 44 (256 x 256).  heavy bit 3 (| 8): the epilogue is STORE / RESID, so a last tile row of <= 32 rows is computed outside the tile
+ * 44 (256 x 256) | 22 (128 x 128, two workgroups per CU: T = q * 512 + r).  heavy bit 3 (| 8): the epilogue is STORE / RESID, so a last tile row of <= 32 rows is computed outside the tile
  * grid ("thin tail": ViT fc1's 4112 rows = 16 tile rows + 16 rows) and does not count as tiles. */
 int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
 /* tuning / test hooks.  Option state is PER THREAD (thread-local, like the error string): the first stllm_* call of a host thread reads the
@@ -157,7 +157,8 @@ int stllm_gemm_w4_plan(int M, int N, int K, int heavy, int shape, int* plan5);
  *                  the phased 192|256 x 256 kernel (st-llm_amd/csrc/gemm_p8.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_w4"    = -1 auto = 2 | 0 off | 1 always (cost model picks the tile) | 2 where its plan beats the other kernels' estimates (from 1024 rows on also
  *                  plans whose K-split hides behind >= 1 whole round; below 1024 rows exchange-free plans of ONE partial round only) | 32 / 42 / 34 / 24 / 43 / 33 always,
- *                  192 x 128 / 256 x 128 / 192 x 256 / 128 x 256 / 256 x 192 / 192 x 192 tile (44 = 256 x 256 was retired in round 3: unsupported, falls back):
+ *                  192 x 128 / 256 x 128 / 192 x 256 / 128 x 256 / 256 x 192 / 192 x 192 tile (44 = 256 x 256 was retired in round 3: unsupported, falls back) | 22 (round 5, never chosen
+ *                  automatically): the 128 x 128 tile as TWO workgroups per CU (two waves per SIMD, 80 KiB of LDS each, 512 persistent workgroups, exchange-free plans):
  *                  the one-wave-per-SIMD kernel (st-llm_amd/csrc/gemm_w4.inc; 16-bit dtypes, needs `workspace`)
  *   "gemm_gemv"  = -1 on (M <= 16) | 0 off | 1 only M <= 4 | 2 = -1: the skinny kernels of the decode regime (st-llm_amd/csrc/gemv.hip):
  *                  the 5 beams of demo.py's beam search, small serving batches (5-row step 6.99 -> 4.34 ms on MI355X)

@@ -947,7 +947,7 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   if (p.ws_bytes < kSkFlagBytes + (int64_t)256 * 256 * 256 * 4) return false;
   int split = 1;
   const float est = stllm_gemm_w4_estimate_us(p.M, p.N, p.K, heavy, shape, &split);
-  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24) { *shape = g_w4_mode; return true; }
+  if (g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24 || g_w4_mode == 22) { *shape = g_w4_mode; return true; }
   if (g_w4_mode == 1) return true;
   if (g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_p8_mode == 0) return false;   // a forced / disabled kernel family (tests / experiments) wins
   // Round 2, first version (2-buffer LDS ring): no gain inside bench.py, where the weights come from HBM (proj + fc2 5.39 ms per
@@ -986,7 +986,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
   if constexpr (!Elem<T>::kIsF32) {
     const StllmOptions& o_ = stllm_options();   // this thread's options: env parsed once, before any decision below
     const int gemv_mode = o_.gemm_gemv, g_sk_mode = o_.gemm_sk, g_p8_mode = o_.gemm_p8, g_w4_mode = o_.gemm_w4;
-    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24;   // tests / experiments
+    const bool forced_tiles = g_sk_mode >= 1 || g_p8_mode == 1 || g_p8_mode == 3 || g_p8_mode == 4 || g_w4_mode == 1 || g_w4_mode == 32 || g_w4_mode == 34 || g_w4_mode == 44 || g_w4_mode == 42 || g_w4_mode == 43 || g_w4_mode == 33 || g_w4_mode == 24 || g_w4_mode == 22;   // tests / experiments
     // M <= 8 since round 2: 5-row decode steps 6.99 -> 6.02 ms at Vicuna-7B size (profiles/r02_decode_bench.log)
     if (p.nx) {   // fused RMSNorm operand: only the GEMV kernel computes it
       const int rc = a->epilogue != STLLM_EPI_PATCH ? stllm_gemv_launch(a->dtype, a->epilogue, p, stream) : STLLM_ERR_UNSUPPORTED;

@@ -415,11 +415,12 @@ W4_SHAPES = [(4112 // 2, 4224, 1408), (576, 4096, 4096), (300, 768, 3072), (97, 
              (528, 768, 1408), (596, 384, 256)]   # the last two: a tail of 16 rows past 256-row tiles / 20 rows past 192-row tiles (thin-tail path)
 
 
-@pytest.mark.parametrize("shape", [32, 34, 42, 24])
+@pytest.mark.parametrize("shape", [32, 34, 42, 24, 22])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 def test_gemm_w4(hip, dtype, shape, M, N, K):
-    """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128 and — round 4 — 128 x 256 tiles): whole rounds, remainder-first K-split
+    """one-wave-per-SIMD kernel forced on (192 x 128, 192 x 256, 256 x 256, 256 x 128, — round 4 — 128 x 256 tiles and — round 5, code 22 — the 128 x 128 tile
+    as TWO workgroups per CU, 512 persistent workgroups, exchange-free): whole rounds, remainder-first K-split
     with the end-of-launch reduction, M / N tails (256 x 256 retired in round 3: a forced 44 falls back to the other kernels), (incl. the thin-tail rows computed outside the tile grid), fp32 / GELU / residual
     epilogues, epoch flags, determinism."""
     hip.set_option("gemm_w4", shape)

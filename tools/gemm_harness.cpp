@@ -86,6 +86,10 @@ int main(int argc, char** argv) {
       {"tr_wgrad_qkv", 12288, 4096, 9216, STLLM_EPI_STORE, 0, 1},
       {"tr_wgrad_lm", 32000, 4096, 9216, STLLM_EPI_STORE, 0, 1},
       {"vit_fc1_noact", 4112, 6144, 1408, STLLM_EPI_STORE, 0, 0},   // the fc1 shape without its GELU (epilogue timeline experiments)
+      // round 5, two workgroups per CU on 128 x 128 tiles (w4 tile code 22): shapes whose 128 x 128 tiles make whole rounds of 512
+      {"dual_fc1", 4096, 6144, 1408, STLLM_EPI_STORE, 1, 0},        // 32 x 48 = 1536 tiles = 3 rounds of 512 (256 x 192: 512 tiles = 2 rounds of 256)
+      {"dual_qkv", 4096, 4096, 1408, STLLM_EPI_STORE, 0, 0},        // 1024 tiles = 2 rounds
+      {"dual_fc2", 4096, 2048, 6144, STLLM_EPI_RESID, 0, 0},        // 512 tiles = 1 round, long K
   };
   int dev_lds = 0;
   CK(hipDeviceGetAttribute(&dev_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, 0));
