@@ -244,6 +244,15 @@ def numerics_legs(model, samples, args, sync):
         for _ in range(warm):
             o = model(samples=samples)
         sync()
+        prof = None
+        if name == "fp16" and not args.no_roofline:   # the reference's production dtype gets its own roofline block: calibrate, then sample the dominant symbol
+            from stllm_amd import hip
+            prof = hip.GemmProfiler()
+            prof.start_all()
+            model(samples=samples)
+            sync()
+            cal = prof.summary()
+            prof.start_target(max(cal, key=lambda k: cal[k]["total_ms"]), sampled=True)
         t0 = time.perf_counter()
         for _ in range(steps):
             o = model(samples=samples)
@@ -251,6 +260,14 @@ def numerics_legs(model, samples, args, sync):
         ms = (time.perf_counter() - t0) / steps * 1e3
         out[name] = {"ms_per_step": round(ms, 3), "steps": steps,
                      "parity": parity_vs_fixture(o.logits, float(o.loss.item()))}
+        if prof is not None:
+            t = prof.summary().get(prof.target)
+            prof.stop()
+            if t:
+                ach = t["flops"] / (t["total_ms"] * 1e-3) / 1e12
+                out[name]["roofline"] = {"bound": "mfma", "kernel": prof.target, "achieved": round(ach, 1), "peak": MFMA_PEAK["fp16"], "unit": "TFLOP/s",
+                                         "frac": round(ach / MFMA_PEAK["fp16"], 4), "launches_timed": t["launches"], "avg_launch_ms": round(t["total_ms"] / t["launches"], 5),
+                                         "algorithmic_gflop_per_launch": round(t["flops"] / t["launches"] / 1e9, 2), "traffic": None}
     runtime.set_compute_dtype(args.dtype)
     return out
 

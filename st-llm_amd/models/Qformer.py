@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import Embedding, LayerNorm, Linear, Output, params_fingerprint
+from .layers import Embedding, LayerNorm, Linear, Output, ParamList, params_fingerprint
 
 
 class BertConfig:
@@ -134,10 +134,11 @@ class BertModel(nn.Module):
         self.encoder = BertEncoder(config, device)
         self._packed = {}
         self._carr = {}   # C-side table of the packed layers: rebuilt when they are re-packed
+        self._plist = ParamList(lambda: self.encoder.layer.parameters())
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        fp = params_fingerprint(self.encoder.layer.parameters())
+        fp = params_fingerprint(self._plist.get())
         hit = self._packed.get(dt)
         if hit is None or hit[0] != fp:
             layers = [l.pack(dt) for l in self.encoder.layer]
@@ -157,10 +158,12 @@ class BertModel(nn.Module):
     def repack(self):
         self._packed = {}
         self._carr = {}
+        self._plist.reset()
 
     def _load_from_state_dict(self, *a, **k):
         self._packed = {}
         self._carr = {}
+        self._plist.reset()
         return super()._load_from_state_dict(*a, **k)
 
     # ------------------------------------------------------------------------------------------

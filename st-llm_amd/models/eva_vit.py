@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import LayerNorm, Linear, _dev, params_fingerprint
+from .layers import LayerNorm, Linear, ParamList, _dev, params_fingerprint
 
 
 class Attention(nn.Module):
@@ -101,11 +101,12 @@ class VisionTransformer(nn.Module):
                                       requires_grad=False)
         self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, eps, device) for _ in range(depth)])
         self._packed = {}
+        self._plist = ParamList(lambda: [self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.pos_embed, self.cls_token, *self.blocks.parameters()])
 
     # -- packing ---------------------------------------------------------------------------------
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        fp = params_fingerprint([self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.pos_embed, self.cls_token, *self.blocks.parameters()])
+        fp = params_fingerprint(self._plist.get())
         hit = self._packed.get(dt)
         if hit is None or hit[0] != fp:
             hit = (fp, dict(
@@ -118,9 +119,11 @@ class VisionTransformer(nn.Module):
 
     def repack(self):
         self._packed = {}
+        self._plist.reset()
 
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
         self._packed = {}
+        self._plist.reset()
         interpolate_pos_embed(self, state_dict, prefix + "pos_embed")   # eva_vit.py:435: before the tensors are copied in
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 

@@ -25,6 +25,25 @@ def params_fingerprint(params):
     return (v, a, runtime.gemm_split())   # the "bf16x3" mode shares torch.float32 with the plain verify mode but packs split weights
 
 
+class ParamList:
+    """The flat list of the master parameters a packed-weight cache depends on, built ONCE: walking `module.parameters()` costs ~1.5 us per
+    parameter (435 us for Vicuna's 291, ~1.5 ms per step over the three stacks — a third of the host's enqueue time of a c2 step), reading
+    `_version` / `data_ptr()` off a list 0.2 us.  The Parameter OBJECTS must stay the ones the module was built with: `load_state_dict`, `.to()`,
+    in-place edits and optimizers keep them (and are seen through `_version` / `data_ptr()`); code that assigns a NEW nn.Parameter to a layer
+    must call the model's repack(), which drops this list too."""
+
+    def __init__(self, walk):
+        self._walk, self._ps = walk, None
+
+    def get(self):
+        if self._ps is None:
+            self._ps = list(self._walk())
+        return self._ps
+
+    def reset(self):
+        self._ps = None
+
+
 class Linear(nn.Module):
     """nn.Linear-named holder.  ``forward`` is the generic (unfused) path: y = x @ W^T + b in the current
     compute dtype, fp32 in / fp32 out."""

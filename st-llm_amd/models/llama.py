@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip, pack, runtime
-from .layers import Embedding, Linear, Output, RMSNorm, params_fingerprint
+from .layers import Embedding, Linear, Output, ParamList, RMSNorm, params_fingerprint
 
 
 class LlamaConfig:
@@ -102,10 +102,11 @@ class LlamaModel(nn.Module):
         self._packed = {}
         self._rope = {}
         self._carr = {}   # C-side table of the packed layers (+ the cache it points into): rebuilt when either changes
+        self._plist = ParamList(lambda: self.layers.parameters())
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
-        fp = params_fingerprint(self.layers.parameters())   # a stale packed copy after p.data.copy_ / .to(device) would run silently
+        fp = params_fingerprint(self._plist.get())   # a stale packed copy after p.data.copy_ / .to(device) would run silently
         hit = self._packed.get(dt)
         if hit is None or hit[0] != fp:
             self._packed = {}  # one packed copy at a time (13.5 GB at 7B) ...
@@ -117,10 +118,12 @@ class LlamaModel(nn.Module):
     def repack(self):
         self._packed = {}
         self._carr = {}
+        self._plist.reset()
 
     def _load_from_state_dict(self, *a, **k):
         self._packed = {}
         self._carr = {}
+        self._plist.reset()
         return super()._load_from_state_dict(*a, **k)
 
     def rope(self, S, device):

@@ -427,9 +427,12 @@ class STLLMModel(Blip2Base):
             if "mask" in samples and samples["mask"] is not None:
                 samples["mask"] = torch.as_tensor(samples["mask"])[own]
             clip_sharded = True
-        # ---- host-side plan FIRST: everything below up to encode_img depends on shapes and token ids only, not on a single device result.
-        # Built (and its index tables enqueued for upload) before the encode, it costs no GPU time; built after it — rounds 1-4 — the GPU
-        # sat idle for the tokenizers and _assemble between the projector and the first RMSNorm (profiles/r04_bench_gaps_final.md: 0.65 ms).
+        # ---- the host-side plan (tokenizers, _assemble, index tables) depends on shapes and token ids only, not on a single device result.
+        # Order (round 5): who-prefills-what first (trivial), then the ENCODE is enqueued — two C calls, ~1 ms of host time for >= 10 ms of GPU work —,
+        # then the plan is built and its tables uploaded WHILE the GPU encodes, then pooling + gather.  Rounds 1-4 built the plan after the encode's
+        # per-op Python launches had eaten the host's lead (0.65 ms of idle GPU per step under rocprofv3, profiles/r04_bench_gaps_final.md); building it
+        # BEFORE the encode (first version of this round) hides it in steady state but exposes it whenever the GPU is idle at the start of a step
+        # (a single request, the first step after a synchronisation, a profiler-slowed host: 0.9-1.2 ms, profiles/r05_bench_gaps.md).
         dev = image.device
         T = image.shape[1]
         use_image = bool(T == 1 or image.dim() == 4)        # encode_img's rule (st_llm.py:326-328)
@@ -466,6 +469,11 @@ class STLLMModel(Blip2Base):
                 if "mask" in samples and samples["mask"] is not None:
                     samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
                 B = len(own)
+        # ---- device work, part 1: the encode (+ the team's token exchange) goes out now; the host runs ahead of it ----------------
+        img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
+        assert use_image_enc == use_image
+        if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
+            return None
         plan = None
         if own is None or own:
             kept = [list(range(L)) for _ in range(B)]
@@ -492,11 +500,7 @@ class STLLMModel(Blip2Base):
             if mask is not None:
                 urows, un_a, _ = self._assemble(L, [list(range(L))] * B, instruction, answers, B)
                 plan.update(urows=self._upload_rows(urows, dev), un_a=hip.with_host(un_a, dev))
-        # ---- device work: encode -> pooling -> ONE gather per sequence block ----------------------------------------------
-        img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
-        assert use_image_enc == use_image
-        if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
-            return None
+        # ---- device work, part 2: pooling -> ONE gather per sequence block ------------------------------------------------------------
         if not use_image:
             img_embeds = self.pool_video(img_embeds)
         elif img_embeds.dim() == 3:
