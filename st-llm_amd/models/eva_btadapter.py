@@ -102,6 +102,10 @@ class EVAVisionTransformer_BTAdapter(VisionTransformer):
                   sp_cls_rows=i32(cls_main),
                   arange_bpt=i32(torch.arange(B * P * T)), arange_b=i32(torch.arange(B)),
                   zeros_b=i32(torch.zeros(B)),
+                  # init_input's (pos_embed + time embedding) table: row (p, t) <- pos_embed[1 + p] + BTAdapter_position[t].  Built HERE, once: as
+                  # `torch.arange(...).to(dev)` inside forward_flat they were two pageable host -> device copies per step = two device
+                  # synchronisations in front of the adapter (the host stood still for the 36 plain blocks: 9.9 ms of a 33 ms step, round 5)
+                  pos_of_pt=i32(1 + torch.arange(P).view(P, 1).expand(P, T)), time_of_pt=i32(torch.arange(T).view(1, T).expand(P, T)),
                   # final merge: main row (b,t,l) <- branch row
                   out_src=i32(sp_src), arange_main=i32(torch.arange(B * T * L)))
         self._idx = {key: tb}
@@ -135,7 +139,19 @@ class EVAVisionTransformer_BTAdapter(VisionTransformer):
         nbr = B * P * T
         h = self.embed_flat(x, pk, dt)
         br = None
+        # the blocks in front of the adapter (36 of 39) have no side branch: ONE C call (stllm_vit_blocks) instead of 7 host calls per block — the
+        # per-op loop made config 5's encode host-bound (16 ms of enqueue for a 34 ms step, the stream idle in front of the adapter: round 5)
+        n_plain = self.num_layers - self.depth
+        from . import llama
+        if llama.STACK_ENTRY and n_plain > 0:
+            if "cblocks" not in pk:
+                pk["cblocks"] = hip.vit_block_array(pk["blocks"])
+            hip.vit_blocks(h, pk["blocks"][:n_plain], pk["cblocks"], n_seq=N, seq_len=L, num_heads=H, dtype=dt)
+        else:
+            n_plain = 0
         for i, bp_ in enumerate(pk["blocks"]):
+            if i < n_plain:
+                continue
             block_forward(h, bp_, N, L, H, dt)
             if i < self.num_layers - self.depth:
                 continue
@@ -145,9 +161,7 @@ class EVAVisionTransformer_BTAdapter(VisionTransformer):
             if br is None:
                 # init_input (eva_btadapter.py:209-231): patches + pos_embed (again) + time embedding; CLS averaged
                 # with (BTAdapter_cls + pos_embed[0])
-                pt = hip.gather_rows(pk["pos"], (1 + torch.arange(P).view(P, 1).expand(P, T)).reshape(-1).to(torch.int32).to(dev),
-                                     add=self.BTAdapter_position.weight,
-                                     idx_add=torch.arange(T).view(1, T).expand(P, T).reshape(-1).to(torch.int32).to(dev))
+                pt = hip.gather_rows(pk["pos"], tb["pos_of_pt"], add=self.BTAdapter_position.weight, idx_add=tb["time_of_pt"])
                 hip.gather_rows(h, tb["main_of_bpt"], add=pt, idx_add=tb["pt_of_bpt"], out=new[:nbr])
                 cls_br = hip.gather_rows(self.BTAdapter_cls.view(1, D).float().contiguous(), tb["zeros_b"][:1], add=pk["pos"],
                                          idx_add=tb["zeros_b"][:1])                # BTAdapter_cls + pos_embed[0]
