@@ -859,7 +859,7 @@ def _run(args, world, rank, device, dry):
                 # split operands (stllm_hip.h STLLM_BF16X3) — the tolerance-meeting mode that is not 9.6x slower
                 res["parity"]["split_verify"] = dict(extra_legs["bf16x3"], mode="bf16x3", vs_timed_dtype=round(extra_legs["bf16x3"]["ms_per_step"] / ms_per_step, 2))
                 # "mixed" (round 5): the split mode with the ViT blocks in fp16 — the cheapest combination of the per-stage ladder that stays under the
-                # north star's 1e-2 (profiles/r04_parity_ladder.log); the margin is thin, which is why split_verify stays the reference verify mode
+                # north star's 1e-2 on c2 (profiles/r04_parity_ladder.log) — c3 9.8e-3, c4 1.02e-2: AT the bar, not under it, which is why split_verify stays the reference verify mode
                 res["parity"]["mixed_verify"] = dict(extra_legs["mixed"], mode="mixed: ViT fp16, Q-Former + projector + Llama + lm_head bf16x3",
                                                      vs_timed_dtype=round(extra_legs["mixed"]["ms_per_step"] / ms_per_step, 2))
         if projection is not None:

@@ -10,7 +10,8 @@
              store the weights split.
   "mixed"  — (round 5) "bf16x3" everywhere EXCEPT the ViT blocks, which run in "fp16": the per-stage error ladder (profiles/r04_parity_ladder.log)
              shows the ViT is the stage whose fp16 error stays under the bar (9.5e-3 alone; the Q-Former's is 1.3e-2, Llama's 2.3e-2), and it is
-             45 % of the GEMM time — the step costs 1.9x the bf16 step instead of 2.8x.  The visual encoder enters `vit_scope()` for its forward.
+             45 % of the GEMM time — the step costs 1.8x the bf16 step instead of 2.8x.  Measured at full size: c2 9.4e-3, c3 9.8e-3, c4 1.02e-2 — AT the 1e-2 bar, not
+             safely under it: "bf16x3" stays the verify mode.  The visual encoder enters `vit_scope()` for its forward (the BT-Adapter backbone does not: it stays bf16x3).
 """
 import contextlib
 
