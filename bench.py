@@ -800,15 +800,8 @@ def _run(args, world, rank, device, dry):
             torch.cuda.empty_cache()
         projection = frame_parallel_projection(args, device)
         out = model = None
-    if world > 1 and args.config == "c2" and not args.no_frame_parallel:
-        del model, out
-        sm = None
-        if not dry:
-            torch.cuda.empty_cache()
-        fp_leg = frame_parallel_leg(args, world, rank, device, dry, sync)
-        sm = None
 
-    if rank == 0:
+    def _emit(fp_leg):
         from stllm_amd import parallel
         Lt = 24 if text else 0
         flop_clip = algorithmic_flops(T, S, Lt, S_unmasked=S_un, btadapter=bt)
@@ -892,6 +885,42 @@ def _run(args, world, rank, device, dry):
             res["cpu_baseline"] = cpu_baseline(T, S)
         print(json.dumps(res), flush=True)
 
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
+
+    def emit(fp_leg):
+        """rank 0 prints THE line (once)"""
+        with emit_lock:
+            if emitted[0] or rank != 0:
+                return
+            emitted[0] = True
+        _emit(fp_leg)
+
+    if world > 1 and args.config == "c2" and not args.no_frame_parallel:
+        del model, out
+        sm = None
+        if not dry:
+            torch.cuda.empty_cache()
+        # The c3 block is the one part of this run that has NEVER executed on a multi-GPU node (RCCL point-to-point inside clip teams, kernels of two
+        # processes sharing links): it must not be able to take the headline measurement — already complete at this point — down with it.  A Python
+        # error becomes {"error": ...} in the line; a hang is cut by a watchdog that prints the line without the block and ends the process.
+        fp_done = threading.Event()
+
+        def watchdog():
+            if not fp_done.wait(args.fp_timeout):
+                emit({"error": f"the frame_parallel block did not finish within {args.fp_timeout} s (cut by bench.py's watchdog; the headline above is unaffected)"})
+                sys.stdout.flush()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            fp_leg = frame_parallel_leg(args, world, rank, device, dry, sync)
+        except Exception as ex:   # noqa: BLE001 — reported, not raised: see above (peers still inside a collective end through their own watchdogs)
+            fp_leg = {"error": f"{type(ex).__name__}: {ex}"}
+        fp_done.set()
+        sm = None
+    emit(fp_leg)
+
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -911,6 +940,7 @@ def main():
     ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the c3 frame-parallel strong-scaling block")
     ap.add_argument("--no-projection", action="store_true", help="N = 1: skip the frame_parallel_projection block (c3 and its per-rank shares on this GPU)")
     ap.add_argument("--fp-steps", type=int, default=30, help="timed steps of the c3 block on N ranks (at least 30: pipeline fill / drain < 2 % of the bracket)")
+    ap.add_argument("--fp-timeout", type=float, default=300.0, help="N > 1: seconds the c3 frame_parallel block may take before the watchdog prints the line without it")
     ap.add_argument("--fp-clips", type=int, default=0, help="override the c3 block's clips per batch (debugging / dry runs: 1 clip on 2 ranks = one team of two)")
     ap.add_argument("--fp-steps-1gpu", type=int, default=3, help="timed steps of the c3 block's 1-GPU reference (rank 0 alone)")
     ap.add_argument("--dry-cpu", action="store_true", help="run the rank logic on CPU (gloo, contract backend): plumbing check only")

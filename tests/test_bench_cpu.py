@@ -81,6 +81,14 @@ def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():
     assert not any(oo["plan"]["sp"]) and sorted(len(sh["prefill"]) for sh in oo["shares"]) == [0, 1] and oo["kv_lag_ms_modelled"] == 0
 
 
+def test_bench_watchdog_keeps_the_headline_when_the_frame_parallel_block_stalls():
+    """the c3 block has never run on a multi-GPU node: if it does not finish in --fp-timeout seconds, rank 0 still prints the (complete) headline line,
+    with the reason in place of the block, and every rank exits 0"""
+    res = _run(["--gpus", "2", "--fp-clips", "1", "--fp-timeout", "0.5"])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["ms_per_step"] > 0
+    assert "watchdog" in res["frame_parallel"]["error"]
+
+
 @pytest.mark.parametrize("config", ["c4", "c5"])
 def test_bench_mvm_configs_dry(config):
     """--config c4 / c5 (BASELINE configs[3] / [4]): mask drawn by the package's generator from the seeded numpy stream and injected, two
