@@ -649,6 +649,32 @@ def test_generate_on_device_matches_reference_ids():
     assert hip.gemm_workspace_ok()
 
 
+def test_generate_padded_batch_on_device():
+    """round 5: a padded batch of prompts of different lengths (left-padded, as HF's decoder-only batches are) in ONE generate() call on the device — served by
+    length groups: every row's ids equal its unpadded prompt generated alone (fp32, greedy and 3 beams), the two equal-length rows share a batched call."""
+    from stllm_amd import runtime
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="mean", use_mask=False, mvm_decode=False,
+               qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=1, qf_layers=2, llm_layers=2)
+    with torch.no_grad():
+        model.lm_head.weight.mul_(6.0)
+    lens = [9, 6, 9, 4]
+    prompts = [T(f"gen.ragged{i}", (n, 4096), 0.05).cuda() for i, n in enumerate(lens)]
+    S = max(lens)
+    emb = torch.zeros(len(lens), S, 4096, device="cuda")
+    mask = torch.zeros(len(lens), S, dtype=torch.long)
+    for i, (p_, n) in enumerate(zip(prompts, lens)):
+        emb[i, S - n:] = p_
+        mask[i, S - n:] = 1
+    with runtime.use_dtype("fp32"):
+        for kw in (dict(num_beams=1), dict(num_beams=3, repetition_penalty=1.2)):
+            k = dict(max_new_tokens=5, do_sample=False, min_length=1, **kw)
+            alone = [model.generate(inputs_embeds=p_[None], **k)[0] for p_ in prompts]
+            got = model.generate(inputs_embeds=emb, attention_mask=mask.cuda(), **k)
+            for i, a in enumerate(alone):
+                assert got[i, : a.numel()].tolist() == a.tolist(), (kw, i)
+
+
 @pytest.mark.parametrize("mode,tol", [("fp32", 2e-4), ("bf16", 5e-2)])
 def test_kv_cache_decode_matches_reprefill(mode, tol):
     """§8f rank 1 (decode loop): prefill into the KV cache + one-token decode steps == re-running the prefill on the
