@@ -389,7 +389,12 @@ class AdamW:
 
     def grad_sink(self):
         """name -> this parameter's slice of the flat gradient buffer, shaped like the parameter (None for names that are not optimised):
-        a producer that writes a gradient there (training.loss_and_grads(sink=...)) saves step() the copy."""
+        a producer that writes a gradient there (training.loss_and_grads(sink=...)) saves step() the copy.
+        CONTRACT: tensors produced through the sink ALIAS this buffer.  They are this step's gradients until the next step() — which
+        averages them over the ranks in place — or the next producer run, whichever comes first; keep `.clone()`s to keep values.  A grads dict whose
+        aliasing entries were already consumed by a step() is refused by the next step() instead of silently applying whatever the buffer holds now."""
+        self._sink_live = True      # a producer is about to fill the buffer: its aliasing gradients are valid for ONE step()
+
         def sink(name):
             slot = self._slot.get(name)
             if slot is None:
@@ -412,6 +417,11 @@ class AdamW:
                 self.gflat[off: off + p.numel()].zero_()
             elif not (g.is_contiguous() and g.numel() == p.numel() and g.data_ptr() == self.gflat.data_ptr() + 4 * off):   # else: produced in place (grad_sink)
                 self.gflat[off: off + p.numel()] = g.reshape(-1)
+            elif not getattr(self, "_sink_live", False):
+                raise RuntimeError(f"AdamW.step: the gradient of {name!r} aliases the optimizer's flat buffer but no producer has filled it since the last step() "
+                                   "(a stale grads dict from an earlier train step?): the buffer now holds that step's AVERAGED gradients — re-run "
+                                   "loss_and_grads(sink=optimizer.grad_sink()) or pass clones")
+        self._sink_live = False
         lo = self.rank * self.shard
         if self.world > 1:
             # presence is a property of the AVERAGED gradient: a parameter that got a gradient on ANY rank (mixed image / video
@@ -497,7 +507,8 @@ def trainable_state_dict(model):
 
 
 def train_step(model, samples, optimizer, freeze_btadapter=False, drop_path=None):
-    """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1)."""
+    """One optimisation step (HF Trainer.training_step + optimizer.step for gradient_accumulation_steps = 1).  Returns (loss, loss_mvm, gradient norm) —
+    deliberately NOT the gradients: the LLM's weight gradients live in the optimizer's flat buffer (AdamW.grad_sink) and are consumed by the step."""
     loss, loss_mvm, grads = loss_and_grads(model, samples, freeze_btadapter, drop_path, sink=optimizer.grad_sink())
     norm = optimizer.step(grads)
     invalidate_packed(model)

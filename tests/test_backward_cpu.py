@@ -170,7 +170,12 @@ def test_gradients_produced_in_the_optimizer_buffer_are_the_same_gradients():
         for n, off, p in zip(opt.names, opt.offsets, opt.params):
             assert torch.equal(opt.gflat[off: off + p.numel()].view(p.shape), want[n]), n
         assert abs(norm - float(torch.sqrt(sum((g.double() ** 2).sum() for g in want.values())))) <= 1e-4 * norm
-        l1, _, _ = training.train_step(model, samples, opt)  # the second step: every slot overwritten, nothing stale, nothing NaN
+        # a STALE grads dict: its aliasing entries were consumed by the step above — a second step() with it would silently apply whatever
+        # the buffer holds now; it is refused instead.  Clones, and a fresh producer run, are fine.
+        with pytest.raises(RuntimeError, match="aliases the optimizer's flat buffer"):
+            opt.step(got)
+        opt.step({n: g.clone() for n, g in got.items()})
+        l1, _, _ = training.train_step(model, samples, opt)  # the next step: every slot overwritten, nothing stale, nothing NaN
         assert torch.isfinite(opt.gflat).all() and torch.isfinite(l1)
     assert opt.grad_sink()("no.such.parameter") is None
 
