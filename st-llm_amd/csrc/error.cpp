@@ -44,6 +44,7 @@ StllmOptions& stllm_options() {
     o.attn_dma = env_int("STLLM_ATTN_DMA", 1);
     o.attn_bwd_valu = env_int("STLLM_ATTN_BWD_VALU", 0);
     o.norm_fast = env_int("STLLM_NORM_FAST", 1);
+    o.gemm_t1 = env_int("STLLM_GEMM_T1", -1);
     o.gemm_w4_odd = env_int("STLLM_GEMM_W4_ODD", 1);
     o.gemm_w4_wide = env_int("STLLM_GEMM_W4_WIDE", 1);
     o.attn_f32_mfma = env_int("STLLM_ATTN_F32_MFMA", 1);
@@ -65,6 +66,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "attn_dma")) { o.attn_dma = value; return STLLM_OK; }
   if (!strcmp(key, "attn_bwd_valu")) { o.attn_bwd_valu = value; return STLLM_OK; }
   if (!strcmp(key, "norm_fast")) { o.norm_fast = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_t1")) { o.gemm_t1 = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_odd")) { o.gemm_w4_odd = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_wide")) { o.gemm_w4_wide = value; return STLLM_OK; }
   if (!strcmp(key, "attn_f32_mfma")) { o.attn_f32_mfma = value; return STLLM_OK; }

@@ -997,6 +997,26 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       const int rc = stllm_gemv_launch(a->dtype, a->epilogue, p, stream);
       if (rc != STLLM_ERR_UNSUPPORTED) return rc;
     }
+    // Tall-tile one-round kernel (gemm_t1.inc, round 6): prefill-sized problems whose 144-row tiles fill ONE round of the 256 CUs with the
+    // whole K extent per workgroup — the Llama o_proj / down GEMMs at 576 rows as 4 x 64 = 256 tiles of 144 x 64 (nothing exchanged between
+    // workgroups; the other kernels split K over 2.7-5 workgroups per tile there).  STLLM_GEMM_T1 = 2 / 4: forced wherever eligible (tests).
+    if (o_.gemm_t1 != 0 && (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_NONE))) {
+      int t1_shape = 0;
+      if (o_.gemm_t1 > 0) t1_shape = o_.gemm_t1;
+      else if (!forced_tiles && p.M >= 128 && p.M <= 1152 && p.K <= 6144) {   // (K = 11008, the down projection: 56-64 us in the harness but 88 us inside the model with cold weights,
+                                                                              //  against 71 us on the phased kernel — profiles/r06_bench_ab_t1.log; o_proj: 38 vs 44 us in the model)
+        const int tm = (p.M + 143) / 144;
+        for (int s = 2; s <= 4 && !t1_shape; s += 2) {
+          const int tiles = tm * (p.N / (32 * s));
+          if (p.N % (32 * s) == 0 && tiles >= 208 && tiles <= 256 && tm * 144 - p.M < 72) t1_shape = s;
+        }
+      }
+      if (t1_shape) {
+        const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_t1_launch_bf16(a->epilogue, t1_shape, p, stream)
+                                                      : stllm_gemm_t1_launch_f16(a->epilogue, t1_shape, p, stream);
+        if (rc != STLLM_ERR_UNSUPPORTED) return rc;
+      }
+    }
     int miw = 4;
     const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
                     : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;

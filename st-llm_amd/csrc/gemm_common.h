@@ -67,4 +67,7 @@ float stllm_gemm_p8_estimate_us(int M, int N, int K, int heavy_epilogue, int* mi
 // same workspace, same epilogues and return codes as the phased kernel
 int stllm_gemm_w4_launch_bf16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
 int stllm_gemm_w4_launch_f16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
+// tall-tile one-round kernel (gemm_t1.inc): 144-row tiles x 32 shape columns, whole K per workgroup, no workspace; STORE (no activation) / RESID
+int stllm_gemm_t1_launch_bf16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
+int stllm_gemm_t1_launch_f16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
 float stllm_gemm_w4_estimate_us(int M, int N, int K, int heavy_epilogue, int* shape, int* split);   // split = K slices of the remainder tiles (1: none)

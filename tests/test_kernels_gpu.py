@@ -450,6 +450,87 @@ def test_gemm_w4(hip, dtype, shape, M, N, K):
         hip.set_option("gemm_w4", -1)
 
 
+T1_SHAPES = [(576, 4096, 4096), (288, 1024, 1408), (300, 512, 2816), (577, 256, 1536), (144, 128, 1408), (17, 128, 1408), (1000, 384, 3072)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", T1_SHAPES)
+def test_gemm_t1_tall_tile(hip, dtype, M, N, K):
+    """round 6: the tall-tile one-round kernel (gemm_t1.inc: 144 x 64 tiles, whole K per workgroup, 4 compute + 4 loader waves, asm MFMAs
+    with tied accumulators) forced on: fp32 / 16-bit stores and the residual epilogue, with and without bias, row tails (M % 144), determinism
+    (nothing is exchanged between workgroups: bit-identical across launches by construction, asserted all the same)."""
+    hip.set_option("gemm_t1", 2)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        a2, a264 = rnd("a_other", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True)
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_t1_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},2,STORE,0,1>")
+        check(out, ref, ACC_TOL[dtype], "t1 store f32")
+        for rep in range(2):
+            check(hip.gemm(a2, w, dtype=dtype, bias=b.cuda(), out_f32=True), a264 @ w64.t() + b.double(), ACC_TOL[dtype], f"t1 store f32 (other operand, rep {rep})")
+            assert torch.equal(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True), out), "t1: not bit-identical across launches"
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda()), ref, OUT_TOL[dtype], "t1 store T")
+        check(hip.gemm(a, w, dtype=dtype), a64 @ w64.t(), OUT_TOL[dtype], "t1 store T, no bias")
+        x = T("x", (M, N), 2.0)
+        xd = x.cuda()
+        for rep in range(2):
+            hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, bias=b.cuda(), resid=xd)
+            assert hip.lib().stllm_last_kernel().decode().startswith("gemm_t1_kernel<")
+        check(xd, x.double() + 2 * ref, ACC_TOL[dtype], "t1 resid x2 (in place)")
+        o2 = torch.empty_like(xd)
+        hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, resid=xd, out=o2)
+        check(o2, x.double() + 2 * ref + a64 @ w64.t(), ACC_TOL[dtype], "t1 resid out of place, no bias")
+        # shapes / epilogues the kernel does not have fall through to the other kernels and stay correct
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU), O.gelu(ref), OUT_TOL[dtype], "forced t1, GELU -> fallback")
+        assert not hip.lib().stllm_last_kernel().decode().startswith("gemm_t1")
+    finally:
+        hip.set_option("gemm_t1", -1)
+
+
+def test_gemm_t1_two_level_rows_and_fallback_k(hip):
+    """the tall-tile kernel with 2-level A rows (frames inside a larger buffer) and 2-level output rows; K % 128 != 0 or fewer than 11 K units
+    are refused (the dispatcher falls back)."""
+    hip.set_option("gemm_t1", 2)
+    try:
+        dtype = "bf16"
+        nb, rpb, K, N = 5, 61, 1408, 256
+        buf, buf64 = rnd("a_buf", (nb, rpb + 3, K), dtype, 0.5)   # batches of rpb rows, 3 unused rows behind each
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        M = nb * rpb
+        ref = (buf64[:, :rpb].reshape(M, K) @ w64.t())   # (the kernel addresses A by (rows per batch, batch stride) inside the larger buffer)
+        out = torch.zeros(nb, rpb + 2, N, device="cuda")    # 2-level output rows too: 2 unused rows behind every batch stay zero
+        hip.gemm(buf, w, dtype=dtype, out=out, out_f32=True, M=M, a_rows=(rpb, (rpb + 3) * K), o_rows=(rpb, (rpb + 2) * N))
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemm_t1_kernel<")
+        check(out[:, :rpb].reshape(M, N), ref, ACC_TOL[dtype], "t1 two-level A / output rows")
+        assert float(out[:, rpb:].abs().max()) == 0.0
+        for Kbad in (704, 1344):   # 11 units (odd), 21 units
+            a, a64 = rnd("a", (200, Kbad), dtype, 0.5)
+            w2, w264 = rnd("w2", (N, Kbad), dtype, 0.05)
+            check(hip.gemm(a, w2, dtype=dtype, out_f32=True), a64 @ w264.t(), ACC_TOL[dtype], f"K = {Kbad}: fallback")
+            assert not hip.lib().stllm_last_kernel().decode().startswith("gemm_t1")
+    finally:
+        hip.set_option("gemm_t1", -1)
+
+
+def test_llama_o_proj_runs_on_the_tall_tile_kernel(hip):
+    """automatic dispatch (round 6): 576 x 4096 x 4096 with the residual epilogue = 4 x 64 tiles of 144 x 64 on gemm_t1 (38 vs 44 us inside the model);
+    the down projection (K = 11008) stays on the phased kernel (88 vs 71 us inside the model, profiles/r06_bench_ab_t1.log)."""
+    dtype = "bf16"
+    for K, want_t1 in ((4096, True), (11008, False)):
+        a, a64 = rnd("a", (576, K), dtype, 0.5)
+        w, w64 = rnd("w", (4096, K), dtype, 0.02)
+        x = T("x", (576, 4096), 2.0)
+        xd = x.cuda()
+        hip.gemm(a, w, dtype=dtype, epilogue=hip.EPI_RESID, resid=xd)
+        name = hip.lib().stllm_last_kernel().decode()
+        assert name.startswith("gemm_t1_kernel<bf16_t,2,RESID") == want_t1, name
+        check(xd, x.double() + a64 @ w64.t(), ACC_TOL[dtype], f"o / down at K = {K} [{name}]")
+    assert hip.gemm_workspace_ok()
+
+
 W4_ODD_SHAPES = [(4112 // 2, 4224, 1408), (576, 1536, 4096), (300, 768, 3072), (97, 384, 6144), (1, 384, 128 * 7), (3072, 2304, 704),
                  (528, 768, 1408), (596, 384, 256)]   # N % 384 == 0 (stllm_gemm wants N % 128 == 0, the tiles N % 192 == 0); the last two: thin tails past 256-row / 192-row tiles
 
