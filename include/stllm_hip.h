@@ -126,6 +126,12 @@ typedef struct {
    *   STLLM_SPLIT_OUT (STORE and SWIGLU epilogues): `out` receives the split image of the result, bf16 [M, ldo >= 3 N'] (N' = N, or N / 2 for SWIGLU), after the
    *     activation — the A operand of the next GEMM — instead of the fp32 tensor.  The values are bit-identical to splitting the fp32 result afterwards. */
   int split_flags;
+  /* optional, ABI version >= 7 (16-bit dtypes; STORE without activation, SWIGLU, ROPE): a FRAGMENT-MAJOR copy of W — [N / 32][K / 16][64 lanes][8 elements],
+   * lane l of fragment (nb, ks) = W[32 nb + (l & 31)][16 ks + 8 (l >> 5) .. + 7], i.e. one contiguous KiB per v_mfma_f32_32x32x16 operand
+   * (st-llm_amd/pack.py: frag32).  When present (N % 256 == 0, K % 256 == 0) prefill-sized problems may run on the W-direct kernel (csrc/gemm_wd.inc):
+   * W fragments go straight into registers, only A is staged through the LDS.  W itself must still be valid (other shapes / kernels read it).
+   * Replaces nothing in the reference: a layout of the nn.Linear weight of modeling_llama_mem.py:130-144, 172-248. */
+  const void* w_frag;
 } stllm_gemm_args;
 enum { STLLM_SPLIT_A_PRESPLIT = 1, STLLM_SPLIT_OUT = 2 };
 int64_t stllm_gemm_split_ws_bytes(int M, int N, int K, int epilogue, int split_flags);
@@ -219,6 +225,7 @@ typedef struct {
   const float* ln1; const void* wqkv; int64_t ld_qkv; const void* wo; int64_t ld_o;
   const float* ln2; const void* wgu; int64_t ld_gu; const void* wdown; int64_t ld_down;
   void* kv_cache;
+  const void* wqkv_frag; const void* wgu_frag;   /* ABI >= 7: NULL or the fragment-major copies of wqkv / wgu (stllm_gemm_args.w_frag) */
 } stllm_llama_layer_weights;
 typedef struct {
   int dtype; int B; int S; int n_heads; int hidden; int inter; float eps;

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstllm_hip.so")
-SOURCES = ["gemm.hip", "gemm_p8_bf16.hip", "gemm_p8_f16.hip", "gemm_w4_bf16.hip", "gemm_w4_f16.hip", "gemm_t1_bf16.hip", "gemm_t1_f16.hip", "gemv.hip", "norm.hip", "attention.hip", "elementwise.hip", "split3.hip", "preprocess.hip", "train_ops.hip", "attention_bwd.hip", "error.cpp", "stacks.cpp", "profile.cpp"]
+SOURCES = ["gemm.hip", "gemm_p8_bf16.hip", "gemm_p8_f16.hip", "gemm_w4_bf16.hip", "gemm_w4_f16.hip", "gemm_t1_bf16.hip", "gemm_t1_f16.hip", "gemm_wd_bf16.hip", "gemm_wd_f16.hip", "gemv.hip", "norm.hip", "attention.hip", "elementwise.hip", "split3.hip", "preprocess.hip", "train_ops.hip", "attention_bwd.hip", "error.cpp", "stacks.cpp", "profile.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

@@ -23,7 +23,7 @@ void stllm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* stllm_last_error(void) { return g_err; }
-extern "C" int stllm_abi_version(void) { return 6; }   // 6 (round 5): stllm_qformer_layers (the third whole-stack family).  5 (round 4): STLLM_BF16X3 + stllm_gemm_args.split_ws / stllm_split3_rows / stllm_gemm_split_ws_bytes; the fold_* fields, stllm_row_stats and stllm_gemm_fold_supported of ABI 4 are gone.  2: stllm_gemm_args gained the trailing a_norm_* fields (round 2); 3: whole-stack entry points, stllm_gemm_profile*, per-thread options; 4: stllm_gemm_args fold_* (LayerNorm folded into the GEMMs), stllm_row_stats (round 3)
+extern "C" int stllm_abi_version(void) { return 7; }   // 7 (round 6): stllm_gemm_args.w_frag, stllm_llama_layer_weights.wqkv_frag / wgu_frag (W-direct GEMM).  6 (round 5): stllm_qformer_layers (the third whole-stack family).  5 (round 4): STLLM_BF16X3 + stllm_gemm_args.split_ws / stllm_split3_rows / stllm_gemm_split_ws_bytes; the fold_* fields, stllm_row_stats and stllm_gemm_fold_supported of ABI 4 are gone.  2: stllm_gemm_args gained the trailing a_norm_* fields (round 2); 3: whole-stack entry points, stllm_gemm_profile*, per-thread options; 4: stllm_gemm_args fold_* (LayerNorm folded into the GEMMs), stllm_row_stats (round 3)
 
 // ---- per-thread dispatch options (common.h) ----
 static int env_int(const char* name, int dflt) {
@@ -45,6 +45,7 @@ StllmOptions& stllm_options() {
     o.attn_bwd_valu = env_int("STLLM_ATTN_BWD_VALU", 0);
     o.norm_fast = env_int("STLLM_NORM_FAST", 1);
     o.gemm_t1 = env_int("STLLM_GEMM_T1", -1);
+    o.gemm_wd = env_int("STLLM_GEMM_WD", -1);
     o.gemm_w4_odd = env_int("STLLM_GEMM_W4_ODD", 1);
     o.gemm_w4_wide = env_int("STLLM_GEMM_W4_WIDE", 1);
     o.attn_f32_mfma = env_int("STLLM_ATTN_F32_MFMA", 1);
@@ -67,6 +68,7 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "attn_bwd_valu")) { o.attn_bwd_valu = value; return STLLM_OK; }
   if (!strcmp(key, "norm_fast")) { o.norm_fast = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_t1")) { o.gemm_t1 = value; return STLLM_OK; }
+  if (!strcmp(key, "gemm_wd")) { o.gemm_wd = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_odd")) { o.gemm_w4_odd = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_wide")) { o.gemm_w4_wide = value; return STLLM_OK; }
   if (!strcmp(key, "attn_f32_mfma")) { o.attn_f32_mfma = value; return STLLM_OK; }

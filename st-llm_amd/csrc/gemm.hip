@@ -953,7 +953,7 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
   // Round 2, first version (2-buffer LDS ring): no gain inside bench.py, where the weights come from HBM (proj + fc2 5.39 ms per
   // step against 5.46 ms); with the 3-buffer ring of the 192 x 128 tile the harness measures the same time on cold weights as on
   // warm ones (tools/gemm_harness ... <cold MiB>, profiles/r02_w4_ring3.md) and the rule below is the default (-1 == 2).
-  if (g_w4_mode != 2 && g_w4_mode != -1 && g_w4_mode != 3) return false;
+  if (g_w4_mode != 2 && g_w4_mode != -1 && g_w4_mode != 3 && g_w4_mode != 4) return false;
   // exchange-free plans only: the one candidate with a K-split that the estimates favour, the Llama qkv GEMM (576 x 12288 x 4096 as
   // 256 whole 192 x 128 tiles + 32 tiles split 8 ways), measured 76.8 vs 81.3 us in the harness but 81.7 us inside bench.py
   // (profiles/r02c_bench_kernel_stats.md) — no gain, so the 128 x 128 kernel keeps it and no model GEMM depends on a w4 exchange
@@ -975,7 +975,11 @@ static bool w4_wanted(const GemmParams& p, int heavy, int* shape, float p8_est_u
       if (stllm_gemm_w4_plan(p.M, p.N, p.K, heavy, kEven[i], q5) != STLLM_OK || q5[2] != 1 || q5[0] != 0) continue;   // ONE partial round (q = 0): the audited case (lm_head as 2.9 rounds of 192 x 128 lost 24 us to the phased kernel)
       if ((float)q5[4] < best) { best = (float)q5[4]; *shape = kEven[i]; }
     }
-    return best < 0.97f * other;
+    if (best < 0.97f * other) return true;
+    // A/B switch (STLLM_GEMM_W4 = 4, round 6): plans with ONE whole round + a K-split remainder below 1024 rows too — the Llama gate / up GEMM at 576 rows is
+    // 258 tiles of 192 x 256 = one round + 2 tiles split 32 ways inside an XCD (the phased kernel runs the same plan at 1.25 us per unit, this kernel at 1.10)
+    if (g_w4_mode == 4 && split != 1 && plan5[0] >= 1 && est < 0.97f * other) return true;
+    return false;
   }
   if (split != 1 && plan5[0] < 1) return false;
   return est < 0.97f * other;
@@ -1017,6 +1021,24 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
         if (rc != STLLM_ERR_UNSUPPORTED) return rc;
       }
     }
+    // W-direct kernel (gemm_wd.inc, round 6): the caller supplied the fragment-major copy of W and the (32 WM) x 256 tiles make ONE round of the chip —
+    // the Llama qkv GEMM at 576 rows as 5 x 48 = 240 tiles of 128 x 256.  STLLM_GEMM_WD = 4 / 6: forced wherever eligible (tests) | 0: off.
+    if (o_.gemm_wd != 0 && p.Wf != nullptr && (a->epilogue == STLLM_EPI_ROPE || a->epilogue == STLLM_EPI_SWIGLU || (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_NONE))) {
+      int wd_shape = 0;
+      if (o_.gemm_wd > 0) wd_shape = o_.gemm_wd;
+      else if (!forced_tiles && p.M >= 128 && p.M <= 1536 && p.N % 256 == 0) {
+        const int cands[2] = {4, 6};
+        for (int ci = 0; ci < 2 && !wd_shape; ++ci) {
+          const int bm = 32 * cands[ci], tmr = (p.M + bm - 1) / bm, tiles = tmr * (p.N / 256);
+          if (tiles >= 200 && tiles <= 256 && tmr * bm - p.M <= bm / 2) wd_shape = cands[ci];
+        }
+      }
+      if (wd_shape) {
+        const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_wd_launch_bf16(a->epilogue, wd_shape, p, stream)
+                                                      : stllm_gemm_wd_launch_f16(a->epilogue, wd_shape, p, stream);
+        if (rc != STLLM_ERR_UNSUPPORTED) return rc;
+      }
+    }
     int miw = 4;
     const int heavy = (a->epilogue == STLLM_EPI_STORE && a->act == STLLM_ACT_GELU) ? 2
                     : (a->epilogue == STLLM_EPI_RESID || (a->epilogue == STLLM_EPI_STORE && a->out_is_f32)) ? 1 : 0;
@@ -1035,7 +1057,7 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
       // exchanged — 576 x 12288 x 4096: 5 x 48 = 240 tiles, 68.8-72 us against 80-82 us on the 128 x 128 kernel (480 tiles = 1.9 rounds) in the
       // harness, profiles/r04_w4_128x256_qkv.md (the vendor library picks the same macro tile for this shape)
       // (any epilogue: the split verify mode's inner GEMM of the same layer is a plain fp32 store at K' = 3 K — 175 vs 230 us on this tile, profiles/r04_gemm_dispatch_audit_x3.log)
-      if (!w4_go && (g_w4_mode == -1 || g_w4_mode == 2 || g_w4_mode == 3) && o_.gemm_w4_wide && p.M <= 640 && !forced_tiles && p.ws != nullptr &&
+      if (!w4_go && (g_w4_mode == -1 || g_w4_mode == 2 || g_w4_mode == 3 || g_w4_mode == 4) && o_.gemm_w4_wide && p.M <= 640 && !forced_tiles && p.ws != nullptr &&
           p.ws_bytes >= kSkFlagBytes + (int64_t)256 * 256 * 256 * 4 && p.N % 256 == 0) {
         const int t24 = ((p.M + 127) / 128) * (p.N / 256);
         if (t24 >= 192 && t24 <= 256) { shape = 24; w4_go = true; }
@@ -1122,6 +1144,7 @@ extern "C" int stllm_gemm(const stllm_gemm_args* a, void* stream_) {
   p.debug = stllm_options().gemm_debug;
   p.ws = reinterpret_cast<char*>(a->workspace); p.ws_bytes = a->workspace_bytes;
   p.nx = a->a_norm_x; p.nx_ld = a->a_norm_ldx; p.ngamma = a->a_norm_gamma; p.neps = a->a_norm_eps;
+  p.Wf = reinterpret_cast<const char*>(a->w_frag);
   p.a_rpb = a->a_rows_per_batch; p.a_bs_b = a->a_batch_stride * eb;
   p.o_rpb = a->o_rows_per_batch; p.o_bs = a->o_batch_stride;
   const int prof_rec = stllm_prof_begin(a, stream_);   // profile.cpp: HIP events around this launch when the caller asked for them

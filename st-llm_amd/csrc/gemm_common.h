@@ -23,6 +23,7 @@ struct GemmParams {
   int o_rpb; int64_t o_bs;         // out 2-level rows (elements)
   int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
   const float* nx; int64_t nx_ld; const float* ngamma; float neps;   // GEMV only: A := RMSNorm(nx) * ngamma (fp32 rows, stride nx_ld elements)
+  const char* Wf;                  // gemm_wd only: fragment-major copy of W (pack.frag32: [N / 32][K / 16][64 lanes x 16 B]) or nullptr
   int w4_thin;                     // gemm_w4 only: the last M % tile_rows (<= 32) rows are computed outside the tile grid (0 = none)
 };
 
@@ -70,4 +71,7 @@ int stllm_gemm_w4_launch_f16(int epilogue, int shape, const sg::GemmParams& p, h
 // tall-tile one-round kernel (gemm_t1.inc): 144-row tiles x 32 shape columns, whole K per workgroup, no workspace; STORE (no activation) / RESID
 int stllm_gemm_t1_launch_bf16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
 int stllm_gemm_t1_launch_f16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
+// W-direct kernel (gemm_wd.inc): (32 shape) x 256 tiles, A through the LDS, W fragments straight into registers from GemmParams::Wf; STORE (no activation) / SWIGLU / ROPE
+int stllm_gemm_wd_launch_bf16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
+int stllm_gemm_wd_launch_f16(int epilogue, int shape, const sg::GemmParams& p, hipStream_t stream);
 float stllm_gemm_w4_estimate_us(int M, int N, int K, int heavy_epilogue, int* shape, int* split);   // split = K slices of the remainder tiles (1: none)

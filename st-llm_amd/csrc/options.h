@@ -14,6 +14,7 @@ struct StllmOptions {
   int gemm_w4_wide;        // STLLM_GEMM_W4_WIDE: 1 (default) prefill-sized GEMMs (<= 640 rows) whose 128 x 256 tiles fill ONE round (192..256 tiles: the Llama qkv GEMM at 385..640 rows) run on the one-wave kernel's 128 x 256 tile | 0 the 128 x 128 kernel (round 1-3)
   int attn_f32_mfma;       // STLLM_ATTN_F32_MFMA: 1 (default) fp32 attention on the exact-fp32 matrix-core kernel from 8 query rows on | 0 the vector kernel (round 1-3) everywhere
   int gemm_t1;             // STLLM_GEMM_T1: -1 auto | 0 off | 2 / 4 / 6 force the tall-tile one-round kernel (gemm_t1.inc) with that many column fragments per wave wherever it is eligible
+  int gemm_wd;             // STLLM_GEMM_WD: -1 auto | 0 off | 4 / 6 force the W-direct kernel (gemm_wd.inc) with that many 32-row fragments per tile wherever it is eligible
   int norm_fast;           // STLLM_NORM_FAST: 1 (default) one row per wave | 2 two rows per wave for >= 2048 short rows (bit-identical; measured equal: 22.36 / 22.47 / 22.41 / 22.40 ms per step)
 };
 StllmOptions& stllm_options();

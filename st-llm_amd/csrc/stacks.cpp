@@ -186,6 +186,7 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
     stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = ldh; g.W = w.wqkv; g.ldw = w.ld_qkv;
     if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT;
+    else g.w_frag = w.wqkv_frag;
     g.aux0 = a->rope_cos; g.aux1 = a->rope_sin; g.rope_seq = a->S; g.rope_cols = 2 * D; g.M = M; g.N = 3 * D; g.K = D; g.ldo = 3 * D;
     char* qkv = qkv_s;
     int64_t bs = (int64_t)a->S * 3 * D;
@@ -208,6 +209,7 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);
     g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = ldh; g.W = w.wgu; g.ldw = w.ld_gu;
     if (x3) g.split_flags = STLLM_SPLIT_A_PRESPLIT | STLLM_SPLIT_OUT;   // SiLU(gate) * up leaves as the split A operand of down_proj
+    else g.w_frag = w.wgu_frag;
     g.out = gu; g.ldo = ldg; g.M = M; g.N = 2 * a->inter; g.K = D;
     STACK_TRY(stllm_gemm(&g, stream));
     g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, sws, sws_bytes);

@@ -47,7 +47,7 @@ class GemmArgs(ctypes.Structure):
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float),
-                ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("split_flags", c_int)]
+                ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("split_flags", c_int), ("w_frag", c_void_p)]
 
 
 class VitBlockWeights(ctypes.Structure):
@@ -68,7 +68,7 @@ class VitBlocksArgs(ctypes.Structure):
 class LlamaLayerWeights(ctypes.Structure):
     _fields_ = [("ln1", c_void_p), ("wqkv", c_void_p), ("ld_qkv", c_int64), ("wo", c_void_p), ("ld_o", c_int64),
                 ("ln2", c_void_p), ("wgu", c_void_p), ("ld_gu", c_int64), ("wdown", c_void_p), ("ld_down", c_int64),
-                ("kv_cache", c_void_p)]
+                ("kv_cache", c_void_p), ("wqkv_frag", c_void_p), ("wgu_frag", c_void_p)]
 
 
 class LlamaLayersArgs(ctypes.Structure):
@@ -420,7 +420,7 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None, a_norm=None, a_presplit=False, out_split=False):
+         a_rows=None, o_rows=None, a_norm=None, a_presplit=False, out_split=False, w_frag=None):
     """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
     dtype fp32 with a bf16 weight of 3 K columns (pack.split3_weight: the runtime's "bf16x3" mode) selects STLLM_BF16X3: a and every output
     stay fp32, the product runs as three bf16 matrix-core passes (stllm_hip.h).  In that mode a_presplit = a is ALREADY the split image bf16 [M, 3 K]
@@ -467,6 +467,11 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
             M = a.shape[0]
         args.A, args.lda = _p(a), a.stride(-2)
     args.W, args.ldw = _p(w), w.stride(0)
+    if w_frag is not None:   # pack.frag32(w): the fragment-major copy (W-direct kernel)
+        _req(w_frag, td, "w_frag")
+        if w_frag.numel() != w.shape[0] * K:
+            raise RuntimeError("gemm: w_frag must hold N x K elements (pack.frag32 of the un-padded weight)")
+        args.w_frag = _p(w_frag)
     if bias is not None:
         _req(bias, torch.float32, "bias")
     args.bias = _p(bias)
@@ -580,6 +585,8 @@ def llama_layer_array(layers, cache=None):
         w.wgu, w.ld_gu = pk["wgu"].data_ptr(), pk["wgu"].stride(0)
         w.wdown, w.ld_down = pk["wdown"].data_ptr(), pk["wdown"].stride(0)
         w.kv_cache = cache.qkv[i].data_ptr() if cache is not None else None
+        w.wqkv_frag = pk["wqkv_frag"].data_ptr() if pk.get("wqkv_frag") is not None else None   # pack.frag32 copies (W-direct GEMM, 16-bit dtypes)
+        w.wgu_frag = pk["wgu_frag"].data_ptr() if pk.get("wgu_frag") is not None else None
     return arr
 
 

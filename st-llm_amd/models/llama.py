@@ -25,6 +25,12 @@ from .. import hip, pack, runtime
 from .layers import Embedding, Linear, Output, ParamList, RMSNorm, params_fingerprint
 
 
+def _frag(pk, key):
+    """keyword of hip.gemm for the fragment-major copy of pk[key], when the pack made one (pack.frag32_or_none)"""
+    f = pk.get(key + "_frag")
+    return {"w_frag": f} if f is not None else {}
+
+
 class LlamaConfig:
     model_type = "llama"
 
@@ -65,11 +71,15 @@ class LlamaDecoderLayer(nn.Module):
 
     def pack(self, dt, n_heads):
         a, m = self.self_attn, self.mlp
-        return dict(ln1=self.input_layernorm.weight, ln2=self.post_attention_layernorm.weight,
-                    wqkv=pack.llama_qkv(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dt, n_heads),
-                    wo=pack.linear(a.o_proj.weight, dt),
-                    wgu=pack.llama_gate_up(m.gate_proj.weight, m.up_proj.weight, dt),
-                    wdown=pack.linear(m.down_proj.weight, dt))
+        pk = dict(ln1=self.input_layernorm.weight, ln2=self.post_attention_layernorm.weight,
+                  wqkv=pack.llama_qkv(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dt, n_heads),
+                  wo=pack.linear(a.o_proj.weight, dt),
+                  wgu=pack.llama_gate_up(m.gate_proj.weight, m.up_proj.weight, dt),
+                  wdown=pack.linear(m.down_proj.weight, dt))
+        # fragment-major copies for the W-direct prefill GEMM (csrc/gemm_wd.inc, round 6): + 2 x (qkv + gate/up) bytes per layer (8.9 GB at 7B in 16 bits)
+        for k in ("wqkv", "wgu"):
+            pk[k + "_frag"] = pack.frag32_or_none(pk[k]) if dt != torch.float32 else None   # (fp32 / bf16x3: other kernels)
+        return pk
 
 
 def cfg_max_len(cfg):
@@ -190,19 +200,19 @@ class LlamaModel(nn.Module):
         for li_, pk in enumerate(layers):
             h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
             if cache is None:
-                qkv = hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D)
+                qkv = hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D, **_frag(pk, "wqkv"))
                 strides = None
             else:  # the cache buffer is the GEMM's output: rows (b, s) at b*max_len + s
                 qkv = cache.qkv[li_].view(B * cache.max_len, 3 * D)
                 hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=S, rope_cols=2 * D,
-                         out=qkv, M=B * S, o_rows=(S, cache.max_len * 3 * D))
+                         out=qkv, M=B * S, o_rows=(S, cache.max_len * 3 * D), **_frag(pk, "wqkv"))
                 strides = (cache.max_len * 3 * D, 3 * D)
             a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=B, H=H, Sq=S, Skv=S, D=hd,
                               scale=hd ** -0.5, causal=True, kv_len=kv_len, q_strides=strides, k_strides=strides,
                               v_strides=strides)
             hip.gemm(a, pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
             h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
-            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU, **_frag(pk, "wgu"))
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
         return x
 
@@ -244,7 +254,7 @@ class LlamaModel(nn.Module):
             recvs = [(torch.empty((rr[i][1] - rr[i][0], 2 * D), device=dev, dtype=dt), ranks[i], ("kv", li_)) for i in range(j) if rr[i][1] > rr[i][0]]
             works = parallel.p2p_exchange([], recvs, me, group, box) if recvs else []
             h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
-            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos_l, sin_l), rope_seq=n_loc, rope_cols=2 * D, out=qkv[s0:s1])
+            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos_l, sin_l), rope_seq=n_loc, rope_cols=2 * D, out=qkv[s0:s1], **_frag(pk, "wqkv"))
             later = [i for i in range(j + 1, k) if rr[i][1] > rr[i][0]]
             if later:
                 kv = qkv[s0:s1, D:].contiguous()
@@ -256,7 +266,7 @@ class LlamaModel(nn.Module):
             a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=1, H=H, Sq=s1, Skv=s1, D=hd, scale=hd ** -0.5, causal=True)
             hip.gemm(a[s0:s1], pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
             h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
-            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU)
+            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU, **_frag(pk, "wgu"))
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
         for _, ws in pending:
             for w in ws:

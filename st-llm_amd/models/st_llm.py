@@ -136,12 +136,13 @@ class STLLMModel(Blip2Base):
         forward needs two prefills and a loss over rows of both (MVM: use_mask, st_llm.py:71-91) — then the owner prefills alone."""
         from .. import parallel
         _, world, _ = self.frame_parallel
+        tpf = self.tokens_per_frame   # 32 query tokens per frame, 64 pooled patches without the Q-Former (ADVICE r05)
         if self.video_input == "residual":
-            lvis = self.residual_size * 32
+            lvis = self.residual_size * tpf
         elif self.video_input == "mean":
-            lvis = 32
+            lvis = tpf
         else:
-            lvis = T * 32
+            lvis = T * tpf
         return parallel.TeamPlan(n_clips, T, world, sp=self.fp_sp and not self.use_mask, balance=self.fp_balance,
                                  prefill_cost_frames=self.prefill_cost_frames * (lvis + 64) / 576.0)
 
@@ -157,12 +158,13 @@ class STLLMModel(Blip2Base):
     def _prefill_load(self, n_clips, T, world):
         """frames-equivalent of the prefill work of every rank (clip c -> rank c % world), scaled with the visual tokens per clip"""
         from .. import parallel
+        tpf = self.tokens_per_frame   # 32 query tokens per frame, 64 pooled patches without the Q-Former (ADVICE r05)
         if self.video_input == "residual":
-            lvis = self.residual_size * 32
+            lvis = self.residual_size * tpf
         elif self.video_input == "mean":
-            lvis = 32
+            lvis = tpf
         else:
-            lvis = T * 32
+            lvis = T * tpf
         per_clip = self.prefill_cost_frames * (lvis + 64) / 576.0
         return [len(parallel.clips_of_rank(n_clips, r, world)) * per_clip for r in range(world)]
 
@@ -677,10 +679,13 @@ class STLLMForCausalLM(LlamaForCausalLM, BaseModel):
                 for w in parallel.p2p_exchange([(part, ranks[j + 1], ("loss", 0))], [], sp["rank"], sp.get("group"), sp.get("mailbox")):
                     w.wait()
             hip.gemm_workspace_check(logits.device) if logits.is_cuda else None
-            res = Output(loss=part[0], logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
+            # a partial sum must not look like the clip's loss — `loss` is the scalar on the LAST member only and None before it
+            # (the running sum of members 0 .. j stays readable as `loss_partial`)
+            res = Output(loss=part[0] if j + 1 == k else None, logits=logits, past_key_values=None, hidden_states=outputs.hidden_states, attentions=None)
             object.__setattr__(res, "loss_mvm", None)
             object.__setattr__(res, "sp_rows", (s0, s1))            # logits = rows [s0, s1) of the clip's sequence
-            object.__setattr__(res, "loss_complete", j + 1 == k)    # loss = the clip's loss on the last member, a partial sum before it
+            object.__setattr__(res, "loss_complete", j + 1 == k)
+            object.__setattr__(res, "loss_partial", part[0])
             return res
         if labels is not None:  # shifted CE (st_llm.py:125-135)
             lab_h = getattr(labels, "_stllm_host", None)

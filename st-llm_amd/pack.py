@@ -15,6 +15,8 @@ parameter lives on); none changes the mathematical function:
                        wave tile) for the fused SiLU(gate)*up epilogue (modeling_llama_mem.py:143-144).
 * ``bert_qkv`` / ``bert_kv`` — Q-Former query/key/value fused (Qformer.py:127-133).
 """
+import os
+
 import torch
 
 from . import runtime
@@ -80,6 +82,27 @@ def llama_gate_up(wg, wu, dtype):
     u = _cast(wu, dtype)
     k = g.shape[1]   # 3 K in the split mode
     return torch.stack((g.view(n // 32, 32, k), u.view(n // 32, 32, k)), dim=1).reshape(2 * n, k).contiguous()
+
+
+def frag32(w):
+    """fragment-major copy of a packed 16-bit weight [N, K] (N % 32 == 0, K % 16 == 0) for the W-direct GEMM (csrc/gemm_wd.inc, stllm_gemm_args.w_frag):
+    [N / 32][K / 16][64 lanes][8 elements], lane l of fragment (nb, ks) = w[32 nb + (l & 31), 16 ks + 8 (l >> 5) : + 8] — the operand of one
+    v_mfma_f32_32x32x16 as one contiguous KiB."""
+    n, k = w.shape
+    assert n % 32 == 0 and k % 16 == 0 and w.element_size() == 2
+    #            nb      row      ks     half   e            nb ks half row e  -> lane = half * 32 + row
+    return w.reshape(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
+def frag32_or_none(w):
+    """frag32(w) where the W-direct kernel can use it: a 16-bit weight on the GPU with N % 256 == 0 and K % 256 == 0 (un-padded, contiguous rows);
+    STLLM_WD_FRAG=0 in the environment: never (the prefill runs on the other kernels, no second copy of the weights)."""
+    if os.environ.get("STLLM_WD_FRAG", "1") == "0" or not w.is_cuda or w.dim() != 2 or w.element_size() != 2 or not w.is_contiguous():
+        return None
+    n, k = w.shape
+    if n % 256 or k % 256 or n * k * 2 >= (1 << 32):
+        return None
+    return frag32(w)
 
 
 def bert_qkv(q, k, v, dtype):

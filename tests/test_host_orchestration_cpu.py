@@ -3,7 +3,9 @@ indexing, pooling/masking/assembly, MVM branch, Chat path, and the frame-paralle
 (world_size 2) — with the kernel entry points replaced by tests/_cpu_backend.py (plain torch, tests only).
 Compared against the oracle (fp32, 5e-5 relative)."""
 import os
+import queue
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -132,6 +134,16 @@ def _free_port():
     return p
 
 
+def _by_value(item):
+    """tensors -> numpy arrays: a torch.multiprocessing queue sends tensors as shared-memory HANDLES, which are gone when the worker exits before
+    the parent has opened them (the collector then spun for ever); arrays are pickled by value"""
+    return tuple(x.detach().numpy().copy() if isinstance(x, torch.Tensor) else x for x in item)
+
+
+def _tensors(item):
+    return tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in item)
+
+
 def _fp_worker(rank, world, port, cfg_names, q):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -155,7 +167,7 @@ def _fp_worker(rank, world, port, cfg_names, q):
             model.model.stllm_model.set_frame_parallel(rank, world)
             out = model(samples=samples)
         own = model.model.stllm_model.owned_clips
-        q.put((cfg_name, rank, own, out.logits.clone(), single))
+        q.put(_by_value((cfg_name, rank, own, out.logits.clone(), single)))
         if cfg["vit_model"] == "eva_clip_g":
             # one clip per rank: the frame ranges ARE the clips each rank prefills, the all-gather is skipped (parallel.gather_needed)
             samples2, _ = make_inputs(2, 2, cfg["qformer_text_input"])
@@ -165,7 +177,7 @@ def _fp_worker(rank, world, port, cfg_names, q):
                 model.model.stllm_model.set_frame_parallel(rank, world)
                 out2 = model(samples=samples2)
             assert model.model.stllm_model._fp_local_clips
-            q.put((cfg_name + "/one_clip_per_rank", rank, model.model.stllm_model.owned_clips, out2.logits.clone(), single2))
+            q.put(_by_value((cfg_name + "/one_clip_per_rank", rank, model.model.stllm_model.owned_clips, out2.logits.clone(), single2)))
             # image batch (T == 1 -> use_image): forward() does not shard images by clip, every rank prefills the whole batch and
             # must therefore hold EVERY image's tokens — the all-gather may not be skipped although ranges == "clips" 
             samples3, _ = make_inputs(2, 1, cfg["qformer_text_input"])
@@ -175,7 +187,7 @@ def _fp_worker(rank, world, port, cfg_names, q):
                 model.model.stllm_model.set_frame_parallel(rank, world)
                 out3 = model(samples=samples3)
             assert not model.model.stllm_model._fp_local_clips
-            q.put((cfg_name + "/image_batch", rank, None, out3.logits.clone(), single3))
+            q.put(_by_value((cfg_name + "/image_batch", rank, None, out3.logits.clone(), single3)))
             # ONE clip of 4 frames on 2 ranks: a team of two — 2 frames each, the sub-blocks exchanged point-to-point, the prefill sequence-parallel
             # (rank 0: positions [0, s), rank 1: [s, S) with rank 0's K | V rows received per layer), the loss accumulated along the team
             samples4, _ = make_inputs(1, 4, cfg["qformer_text_input"])
@@ -192,8 +204,8 @@ def _fp_worker(rank, world, port, cfg_names, q):
                 frames4 = samples4["image"].reshape(4, 3, 224, 224)
                 qt4 = [it.split("Human: ")[1].split(" ###")[0] for it in samples4["instruction_input"]] * 4 if cfg["qformer_text_input"] else None
                 ref_blk = torch.cat([sm._encode_frames(frames4[a:b], qt4[a:b] if qt4 else None, 4, torch.float32) for a, b in ((0, 2), (2, 4))])
-            q.put((cfg_name + "/team_sp", rank, out4.sp_rows, out4.logits.clone(), single4.logits.clone(),
-                   float(out4.loss), float(single4.loss), bool(out4.loss_complete), bool(torch.equal(blk, ref_blk))))
+            q.put(_by_value((cfg_name + "/team_sp", rank, out4.sp_rows, out4.logits.clone(), single4.logits.clone(),
+                             None if out4.loss is None else float(out4.loss), float(single4.loss), bool(out4.loss_complete), bool(torch.equal(blk, ref_blk)))))
         del model
     dist.barrier()
     dist.destroy_process_group()
@@ -215,11 +227,15 @@ def test_frame_parallel_model_matches_single_process():
         p.start()
     res = []
     n_results = world * (len(cfg_names) + 3)      # + the one-clip-per-rank, the image-batch and the team / sequence-parallel case of the eva_clip_g config
-    while len(res) < n_results:      # a worker that died must fail the test, not hang it
+    deadline = time.monotonic() + 900.0
+    while len(res) < n_results:      # a worker that died — or a result that got lost — must fail the test, not hang it
         try:
-            res.append(q.get(timeout=10))
-        except Exception:
+            res.append(_tensors(q.get(timeout=10)))
+        except queue.Empty:
             assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+            assert any(p.is_alive() for p in procs) or not q.empty() or len(res) >= n_results, \
+                f"both workers exited with {len(res)} of {n_results} results delivered"
+            assert time.monotonic() < deadline, f"no result for 900 s ({len(res)} of {n_results} delivered)"
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -253,6 +269,8 @@ def test_frame_parallel_model_matches_single_process():
         assert complete == (rank == world - 1)
         if complete:
             assert abs(loss - loss1) <= 1e-5, (loss, loss1)
+        else:
+            assert loss is None   # a partial sum never poses as the clip's loss
     extra = [r for r in res if r[0].endswith("/one_clip_per_rank")]
     assert len(extra) == world
     for name, rank, own, logits, single in extra:

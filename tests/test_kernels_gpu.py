@@ -531,6 +531,120 @@ def test_llama_o_proj_runs_on_the_tall_tile_kernel(hip):
     assert hip.gemm_workspace_ok()
 
 
+WD_SHAPES = [(576, 1024, 1024), (130, 256, 256), (300, 512, 4096), (17, 256, 512), (700, 768, 1536)]
+
+
+@pytest.mark.parametrize("wm", [4, 6])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", WD_SHAPES)
+def test_gemm_wd_w_direct(hip, dtype, wm, M, N, K):
+    """round 6: the W-direct kernel (gemm_wd.inc: (32 wm) x 256 tiles, W fragments straight into registers from the fragment-major copy
+    pack.frag32, A through the LDS ring) forced on: fp32 / 16-bit stores with and without bias, row tails, determinism; without w_frag, or
+    with an epilogue it does not have, the dispatcher falls back."""
+    from stllm_amd import pack
+    hip.set_option("gemm_wd", wm)
+    try:
+        a, a64 = rnd("a", (M, K), dtype, 0.5)
+        a2, a264 = rnd("a_other", (M, K), dtype, 0.5)
+        w, w64 = rnd("w", (N, K), dtype, 0.05)
+        wf = pack.frag32(w)
+        b = T("b", (N,), 0.5)
+        ref = a64 @ w64.t() + b.double()
+        out = hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True, w_frag=wf)
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_wd_kernel<{'bf16_t' if dtype == 'bf16' else 'f16_t'},{wm},STORE,0,1>")
+        check(out, ref, ACC_TOL[dtype], "wd store f32")
+        for rep in range(2):
+            check(hip.gemm(a2, w, dtype=dtype, bias=b.cuda(), out_f32=True, w_frag=wf), a264 @ w64.t() + b.double(), ACC_TOL[dtype], f"wd store f32 (other operand, rep {rep})")
+            assert torch.equal(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True, w_frag=wf), out), "wd: not bit-identical across launches"
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), w_frag=wf), ref, OUT_TOL[dtype], "wd store T")
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemm_wd_kernel<")
+        check(hip.gemm(a, w, dtype=dtype, w_frag=wf), a64 @ w64.t(), OUT_TOL[dtype], "wd store T, no bias")
+        # no fragment copy / an epilogue the kernel does not have: the other kernels, same numbers
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), out_f32=True), ref, ACC_TOL[dtype], "forced wd without w_frag -> fallback")
+        assert not hip.lib().stllm_last_kernel().decode().startswith("gemm_wd")
+        check(hip.gemm(a, w, dtype=dtype, bias=b.cuda(), act=hip.ACT_GELU, w_frag=wf), O.gelu(ref), OUT_TOL[dtype], "forced wd, GELU -> fallback")
+        assert not hip.lib().stllm_last_kernel().decode().startswith("gemm_wd")
+    finally:
+        hip.set_option("gemm_wd", -1)
+
+
+@pytest.mark.parametrize("wm", [4, 6])
+def test_gemm_wd_swiglu_rope_rows(hip, wm):
+    """the W-direct kernel's SwiGLU and RoPE epilogues against float64 (the packed layouts of pack.llama_gate_up / pack.llama_qkv), 2-level A and output rows"""
+    from stllm_amd import pack
+    dtype = "bf16"
+    hip.set_option("gemm_wd", wm)
+    try:
+        M, K, I = 333, 1024, 1024 + 128 * 2
+        a, a64 = rnd("a", (M, K), dtype)
+        wg, wg64 = rnd("wg", (I, K), dtype, 0.05)
+        wu, wu64 = rnd("wu", (I, K), dtype, 0.05)
+        wgu = pack.llama_gate_up(wg, wu, dtype)
+        out = hip.gemm(a, wgu, dtype=dtype, epilogue=hip.EPI_SWIGLU, w_frag=pack.frag32(wgu))
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_wd_kernel<bf16_t,{wm},SWIGLU")
+        check(out, F.silu(a64 @ wg64.t()) * (a64 @ wu64.t()), OUT_TOL[dtype], "wd swiglu")
+        B, S, H, D = 2, 150, 4, 128
+        a, a64 = rnd("a2", (B * S, K), dtype)
+        wq, wq64 = rnd("wq", (H * D, K), dtype, 0.05)
+        wk, wk64 = rnd("wk", (H * D, K), dtype, 0.05)
+        wv, wv64 = rnd("wv", (H * D, K), dtype, 0.05)
+        cos, sin = pack.rope_tables(S)
+        wqkv = pack.llama_qkv(wq, wk, wv, dtype, n_heads=H)
+        cache = torch.zeros((B, S + 5, 3 * H * D), device="cuda", dtype=torch.bfloat16)   # the KV-cache form: 2-level output rows
+        hip.gemm(a, wqkv, dtype=dtype, epilogue=hip.EPI_ROPE, rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D, w_frag=pack.frag32(wqkv),
+                 out=cache.view(B * (S + 5), 3 * H * D), M=B * S, o_rows=(S, (S + 5) * 3 * H * D))
+        assert hip.lib().stllm_last_kernel().decode().startswith(f"gemm_wd_kernel<bf16_t,{wm},ROPE")
+        assert float(cache[:, S:].abs().max()) == 0.0
+        qkv = cache[:, :S].double().cpu().view(B, S, 3, H, D)
+        c, s_ = O.rope_tables(S, D)
+        q = (a64 @ wq64.t()).view(B, S, H, D).transpose(1, 2)
+        k = (a64 @ wk64.t()).view(B, S, H, D).transpose(1, 2)
+        q = q * c.double() + O._rotate_half(q) * s_.double()
+        k = k * c.double() + O._rotate_half(k) * s_.double()
+        perm = pack.rope_head_perm(1)
+        check(qkv[:, :, 0].transpose(1, 2), q[..., perm], OUT_TOL[dtype], "wd q rope")
+        check(qkv[:, :, 1].transpose(1, 2), k[..., perm], OUT_TOL[dtype], "wd k rope")
+        check(qkv[:, :, 2], (a64 @ wv64.t()).view(B, S, H, D), OUT_TOL[dtype], "wd v")
+        # 2-level A rows (row groups inside a larger buffer)
+        N_, S2, Q, C, Nout = 5, 44, 32, 768, 256
+        buf, buf64 = rnd("buf", (N_ * S2, C), dtype)
+        w, w64 = rnd("w2", (Nout, C), dtype, 0.05)
+        outb = torch.zeros((N_ * S2, Nout), device="cuda", dtype=torch.float32)
+        hip.gemm(buf, w, dtype=dtype, out=outb, out_f32=True, M=N_ * Q, a_rows=(Q, S2 * C), o_rows=(Q, S2 * Nout), w_frag=pack.frag32(w))
+        assert hip.lib().stllm_last_kernel().decode().startswith("gemm_wd_kernel<")
+        check(outb.view(N_, S2, Nout)[:, :Q].reshape(-1, Nout), buf64.view(N_, S2, C)[:, :Q].reshape(-1, C) @ w64.t(), ACC_TOL[dtype], "wd query rows")
+        assert float(outb.view(N_, S2, Nout)[:, Q:].abs().max()) == 0.0
+    finally:
+        hip.set_option("gemm_wd", -1)
+
+
+def test_llama_prefill_qkv_runs_on_the_w_direct_kernel(hip):
+    """automatic dispatch (round 6): with the fragment-major copy at hand the Llama qkv GEMM at 449..640 rows (5 x 48 = 240 tiles of 128 x 256 = one round)
+    runs on gemm_wd (66.5 vs 74.7 us inside the model, profiles/r06_bench_ab_wd.log); other row counts, and callers without the copy, keep the other kernels.
+    Same numbers either way (1 ulp of the 16-bit output at most)."""
+    from stllm_amd import pack
+    dtype = "bf16"
+    H, D, K = 32, 128, 4096
+    wq, _ = rnd("q24.wq", (H * D, K), dtype, 0.02)
+    wk, _ = rnd("q24.wk", (H * D, K), dtype, 0.02)
+    wv, _ = rnd("q24.wv", (H * D, K), dtype, 0.02)
+    w = pack.llama_qkv(wq, wk, wv, dtype, n_heads=H)
+    wf = pack.frag32_or_none(w)
+    assert wf is not None
+    for S, want in ((576, True), (640, True), (580, True), (448, False), (384, False), (150, False)):
+        a, _ = rnd(f"q24.a{S}", (S, K), dtype)
+        cos, sin = pack.rope_tables(S)
+        kw = dict(dtype=dtype, epilogue=hip.EPI_ROPE, rope=(cos.cuda(), sin.cuda()), rope_seq=S, rope_cols=2 * H * D)
+        out = hip.gemm(a, w, w_frag=wf, **kw)
+        name = hip.lib().stllm_last_kernel().decode()
+        assert name.startswith("gemm_wd_kernel<bf16_t,4,ROPE") == want, (S, name)
+        ref = hip.gemm(a, w, **kw)
+        assert not hip.lib().stllm_last_kernel().decode().startswith("gemm_wd")
+        d = (out.float() - ref.float()).abs()
+        assert float((d / ref.float().abs().clamp(min=1.0)).max()) <= 2 ** -7, (S, float(d.max()))
+    assert hip.gemm_workspace_ok(), hip.lib().stllm_last_error().decode()
+
+
 W4_ODD_SHAPES = [(4112 // 2, 4224, 1408), (576, 1536, 4096), (300, 768, 3072), (97, 384, 6144), (1, 384, 128 * 7), (3072, 2304, 704),
                  (528, 768, 1408), (596, 384, 256)]   # N % 384 == 0 (stllm_gemm wants N % 128 == 0, the tiles N % 192 == 0); the last two: thin tails past 256-row / 192-row tiles
 

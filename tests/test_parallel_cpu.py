@@ -30,7 +30,7 @@ def _worker(rank, world, port, n_frames, q, extra=None):
     torch.manual_seed(0)
     frames = torch.randn(n_frames, 3, 16, 16)
     tokens = parallel.encode_frames_parallel(_encode, frames, rank, world, token_shape=(32, 8), extra=extra)
-    q.put((rank, tokens.clone(), parallel.frame_range(n_frames, rank, world, extra), parallel.clips_of_rank(5, rank, world)))
+    q.put((rank, tokens.numpy().copy(), parallel.frame_range(n_frames, rank, world, extra), parallel.clips_of_rank(5, rank, world)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +53,7 @@ def test_frame_parallel_allgather_matches_single_process(n_frames, extra):
     ref = _encode(torch.randn(n_frames, 3, 16, 16))
     ranges = {}
     for rank, tokens, fr, clips in res:
-        assert torch.equal(tokens, ref), f"rank {rank}: gathered block differs from the 1-process result"
+        assert torch.equal(torch.from_numpy(tokens), ref), f"rank {rank}: gathered block differs from the 1-process result"
         ranges[rank] = fr
         assert clips == [c for c in range(5) if c % world == rank]
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == n_frames
@@ -145,7 +145,7 @@ def _team_worker(rank, world, port, clips, T, sp, q):
     plan = parallel.TeamPlan(clips, T, world, sp=sp, balance="throughput", prefill_cost_frames=1.0)
     local = {c: _encode(frames[c * T + f0: c * T + f1]) for c, f0, f1 in plan.encodes(rank)}
     blocks = parallel.exchange_clip_tokens(local, plan, rank, token_shape=(32, 8))
-    q.put((rank, {c: b.clone() for c, b in blocks.items()}, plan.clips_of(rank)))
+    q.put((rank, {c: b.numpy().copy() for c, b in blocks.items()}, plan.clips_of(rank)))   # arrays: pickled by value (a tensor travels as a shared-memory handle that dies with the worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -172,7 +172,7 @@ def test_clip_team_exchange_matches_single_process(world, clips, T, sp):
     for rank, blocks, own in res:
         assert sorted(blocks) == sorted(own) == plan.clips_of(rank)
         for c, b in blocks.items():
-            assert torch.equal(b, ref[c]), f"rank {rank} clip {c}"
+            assert torch.equal(torch.from_numpy(b), ref[c]), f"rank {rank} clip {c}"
             holders[c].append(rank)
     for c in range(clips):
         assert sorted(holders[c]) == sorted(plan.receivers(c))

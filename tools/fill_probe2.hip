@@ -12,7 +12,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 template <int ROWS, bool SWZ, int DEPTH>
-__global__ __launch_bounds__(256) void fill2(const char* __restrict__ A, const char* __restrict__ W, int ldb, int kbytes, unsigned long long* cyc) {
+__global__ __launch_bounds__(256) void fill2(const char* __restrict__ A, const char* __restrict__ W, int ldb, int kbytes, unsigned long long* cyc, int reps = 1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x, g = (b & 7) * 32 + (b >> 3), tm = g & 3, tn = g >> 2;
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void fill2(const char* __restrict__ A, const c
   char* dst = smem + wave * 8192;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   int issued = 0;
+  for (int rep = 0; rep < reps; ++rep)
   for (int k = 0; k < kbytes; k += SEG) {
     for (int grp = wave; grp < 26; grp += 4) {
 #pragma unroll
@@ -46,34 +47,36 @@ __global__ __launch_bounds__(256) void fill2(const char* __restrict__ A, const c
 }
 
 // the same traffic by plain 16-byte loads into registers (MODE 1: dropped there, 2: + ds_write_b128 into the LDS): is the LDS-DMA path the limit?
+// NW waves per workgroup; wave w takes the 8-row groups w, w + NW, ..; per 128-byte K step it loads its groups (<= 7 loads of 1 KiB per wave in flight), then
+// consumes them — the other waves of the CU cover the wait.
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 template <int ROWS, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void fill_plain(const char* __restrict__ A, const char* __restrict__ W, int ldb, int kbytes, unsigned long long* cyc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x, g = (b & 7) * 32 + (b >> 3), tm = g & 3, tn = g >> 2;
-  constexpr int SEG = 1024 / ROWS, LPR = 64 / ROWS;
-  const int rin = lane / LPR, cin = lane % LPR;
+  static_assert(ROWS == 8, "8-row pieces only");
+  const int rin = lane >> 3, cin = lane & 7;
+  constexpr int NG = (26 + NW - 1) / NW;
+  const char* rowp[NG];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    int grp = wave + NW * gi;
+    grp = grp < 26 ? grp : 25;
+    const int row = grp * 8 + rin;
+    rowp[gi] = (row < 144 ? A + (size_t)(tm * 144 + row) * ldb : W + (size_t)(tn * 64 + row - 144) * ldb) + cin * 16;
+  }
   char* dst = smem + wave * 8192 + lane * 16;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  constexpr int UN = 8;   // loads in flight per wave
-  // flat list of this wave's pieces: (k, grp, pp); UN at a time
-  const int per_k = 8 / ROWS;
-  const int ngrp = (26 - wave + NW - 1) / NW;
-  const int total = (kbytes / SEG) * ngrp * per_k;
-  for (int i0 = 0; i0 < total; i0 += UN) {
-    i32x4 v[UN];
+  for (int k = 0; k < kbytes; k += 256) {   // two K steps per iteration: 2 NG loads in flight per wave
+    i32x4 v[2 * NG];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      int i = i0 + u;
-      i = i < total ? i : total - 1;
-      const int pp = i % per_k, gi = (i / per_k) % ngrp, k = (i / per_k / ngrp) * SEG;
-      const int row = (wave + NW * gi) * 8 + pp * ROWS + rin;
-      const char* base = row < 144 ? A + (size_t)(tm * 144 + row) * ldb : W + (size_t)(tn * 64 + row - 144) * ldb;
-      v[u] = *reinterpret_cast<const i32x4*>(base + k + cin * 16);
+    for (int gi = 0; gi < NG; ++gi) {
+      v[2 * gi] = *reinterpret_cast<const i32x4*>(rowp[gi] + k);
+      v[2 * gi + 1] = *reinterpret_cast<const i32x4*>(rowp[gi] + k + 128);
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
+    for (int u = 0; u < 2 * NG; ++u) {
       if constexpr (MODE == 2) *reinterpret_cast<i32x4*>(dst + (u & 7) * 1024) = v[u];
       else asm volatile("" ::"v"(v[u]));
     }
@@ -95,26 +98,26 @@ static void run_plain(const char* label, const char* A, const char* W, int ldb, 
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= 5;
-  const double bytes = (double)grid * 208.0 * kbytes;
+  const double bytes = (double)grid * (double)(((26 + NW - 1) / NW) * NW * 8) * kbytes;   // (clamped groups re-load the last one)
   printf("%-34s %d waves ld %5d grid %3d: %7.1f GB/s per CU, %6.2f TB/s chip, %7.1f us\n", label, NW, ldb, grid, bytes / (ms * 1e-3) / grid / 1e9, bytes / (ms * 1e-3) / 1e12, ms * 1e3);
 }
 
 template <int ROWS, bool SWZ, int DEPTH>
-static void run(const char* label, const char* A, const char* W, int ldb, int kbytes, unsigned long long* cyc, int grid) {
+static void run(const char* label, const char* A, const char* W, int ldb, int kbytes, unsigned long long* cyc, int grid, int reps = 1) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fill2<ROWS, SWZ, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((fill2<ROWS, SWZ, DEPTH>), dim3(grid), dim3(256), 128 * 1024, 0, A, W, ldb, kbytes, cyc);
+  hipLaunchKernelGGL((fill2<ROWS, SWZ, DEPTH>), dim3(grid), dim3(256), 128 * 1024, 0, A, W, ldb, kbytes, cyc, reps);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fill2<ROWS, SWZ, DEPTH>), dim3(grid), dim3(256), 128 * 1024, 0, A, W, ldb, kbytes, cyc);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((fill2<ROWS, SWZ, DEPTH>), dim3(grid), dim3(256), 128 * 1024, 0, A, W, ldb, kbytes, cyc, reps);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= 5;
-  const double bytes = (double)grid * 208.0 * kbytes;
+  const double bytes = (double)grid * 208.0 * kbytes * reps;
   printf("%-34s depth %2d ld %5d grid %3d: %7.1f GB/s per CU, %6.2f TB/s chip, %7.1f us  (%5.1f cycles per piece and CU at 2.1 GHz)\n", label, DEPTH, ldb, grid, bytes / (ms * 1e-3) / grid / 1e9,
-         bytes / (ms * 1e-3) / 1e12, ms * 1e3, ms * 1e-3 * 2.1e9 / (208.0 * kbytes / 1024.0));
+         bytes / (ms * 1e-3) / 1e12, ms * 1e3, ms * 1e-3 * 2.1e9 / (208.0 * kbytes * reps / 1024.0));
 }
 
 int main() {
@@ -137,12 +140,16 @@ int main() {
   run<8, true, 8>("8 rows x 128 B, chunk swizzle", A, W, 8192, 8192, cyc, 256);
   run<8, true, 32>("8 rows x 128 B, chunk swizzle", A, W, 8192, 8192, cyc, 256);
   run<1, false, 32>("1 row x 1 KiB", A, W, 8192, 8192, cyc, 256);
+  // the same pieces re-reading a 1-KiB-wide K window 8 / 32 times: per XCD 0.6 MB of A + 0.5 MB of W = L2 hits after the first pass (per CU 208 KB: no L1 hits)
+  run<8, true, 16>("8 x 128 B swizzle, L2-resident x8", A, W, 8192, 1024, cyc, 256, 8);
+  run<8, true, 16>("8 x 128 B swizzle, L2-resident x32", A, W, 8192, 1024, cyc, 256, 32);
+  run<8, true, 32>("8 x 128 B swizzle, L2-resident x32", A, W, 8192, 1024, cyc, 256, 32);
+  run<1, false, 16>("1 x 1 KiB, L2-resident x32", A, W, 8192, 1024, cyc, 256, 32);
   run_plain<8, 1, 4>("plain loads 8 x 128 B -> VGPR", A, W, 8192, 8192, cyc, 256);
-  run_plain<1, 1, 4>("plain loads 1 x 1 KiB -> VGPR", A, W, 8192, 8192, cyc, 256);
-  run_plain<8, 2, 4>("plain loads 8 x 128 B -> ds_write", A, W, 8192, 8192, cyc, 256);
   run_plain<8, 1, 8>("plain loads 8 x 128 B -> VGPR", A, W, 8192, 8192, cyc, 256);
+  run_plain<8, 1, 13>("plain loads 8 x 128 B -> VGPR", A, W, 8192, 8192, cyc, 256);
   run_plain<8, 2, 8>("plain loads 8 x 128 B -> ds_write", A, W, 8192, 8192, cyc, 256);
-  run_plain<1, 2, 8>("plain loads 1 x 1 KiB -> ds_write", A, W, 8192, 8192, cyc, 256);
+  run_plain<8, 2, 13>("plain loads 8 x 128 B -> ds_write", A, W, 8192, 8192, cyc, 256);
   run<8, true, 16>("8 rows x 128 B, chunk swizzle", A, W, 8192, 8192, cyc, 128);
   run<1, false, 16>("1 row x 1 KiB", A, W, 8192, 8192, cyc, 128);
   return 0;
