@@ -30,9 +30,22 @@ struct AttnParams {
   float scale;
   int causal;
   const int32_t* kv_len;
+  int q_lds;                            // attn_dma_kernel: the query tiles arrive through the LDS (set by launch_dma when they fit)
+  int merge_par;                        // attn_dma_kernel, KS2 > 1: every partner wave has its own merge slot (one barrier pair instead of one per partner)
 };
 
 constexpr float kNeg = -1.0e30f;
+
+// in-kernel timeline (tools/attn_trace.sh builds st-llm_amd/attn_trace/libstllm_hip.so with -DSTLLM_ATTN_TRACE; never in the shipped library):
+// lane 0 of every wave stamps s_memtime into 8 slots of g_attn_trace[workgroup][wave]; tools/attn_trace.py reads them back.
+#ifdef STLLM_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[512 * 12 * 8];
+#define ATTN_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_attn_trace[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 12 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATTN_STAMP_VAL(slot, val) do { if ((threadIdx.x & 63) == 0) g_attn_trace[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 12 + (threadIdx.x >> 6)) * 8 + (slot)] = (unsigned long long)(val); } while (0)
+#else
+#define ATTN_STAMP(slot) do { } while (0)
+#define ATTN_STAMP_VAL(slot, val) do { } while (0)
+#endif
 
 // XCD-aware (batch, head, query-chunk) assignment.  The hardware deals workgroups round-robin over the 8 XCDs, each with its own
 // L2; with the natural order neighbouring heads of a frame (whose 176-byte K / V rows share cache lines at head_dim 88) and the
@@ -247,6 +260,8 @@ __global__ __launch_bounds__(768) void attn_resident_kernel(const AttnParams p) 
   const int qt = chunk * nwaves + wave;                 // this wave's query tile
   const bool q_live = qt * 32 < p.Sq;
   const int qrow = qt * 32 + li;
+  unsigned long long t_wait = 0;
+  (void)t_wait;
   int kv_block_end = kvlen;                             // keys any wave of this block can see
   if (p.causal) kv_block_end = min(kv_block_end, (chunk + 1) * nwaves * 32);
 
@@ -477,6 +492,7 @@ __device__ __forceinline__ void lds_read_tr_3pairs(const char* p, unsigned long 
 
 template <typename T, int KS2, int DP = 128>
 __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
+  ATTN_STAMP(0);
   // DP = 128: Llama (256-byte rows, 128-key windows); DP = 96: head_dim 88 of the EVA ViT (rows of 11 chunks in a 12-chunk = 192-byte
   // pitch, chunk 11 a copy of chunk 10 that meets zero-padded Q / unstored columns; 96-key windows, two workgroups per CU)
   constexpr int KS = DP / 16, DB = DP / 32, CH = DP / 8, PITCH = CH * 16, W = DP == 128 ? 128 : 96;
@@ -500,11 +516,18 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
   const int qt = chunk * nwaves + wave;
   const bool q_live = qt * 32 < p.Sq;
   const int qrow = qt * 32 + li;
+  unsigned long long t_wait = 0;
+  (void)t_wait;
   int kv_block_end = kvlen;
   if (p.causal) kv_block_end = min(kv_block_end, (chunk + 1) * nwaves * 32);
 
+  // The query fragments.  Straight from global memory every load instruction touches 32 rows = 32 cache lines for 32 bytes each, and the KS2 waves
+  // of a tile fetch the same fragments: 8 x 32 line look-ups per wave at ~4.75 cycles each sat in FRONT of the first K / V window in the CU's
+  // memory pipeline (timeline, tools/attn_trace.py: 7.7 k cycles from the start of a wave to its last request, profiles/r06_attn_trace.md).
+  // p.q_lds: the tile's 32 rows arrive ONCE, row-contiguous, by LDS-DMA (CH / 2 one-KiB pieces shared by the tile's KS2 waves, K's chunk swizzle)
+  // in an image behind the window buffers and are read as fragments after the first barrier.
   i32x4 qf[KS];
-  {
+  if (!p.q_lds) {
     const char* qp = p.q + ((int64_t)b * p.q_bs + (int64_t)(qrow < p.Sq ? qrow : 0) * p.q_rs + (int64_t)h * D) * 2;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -519,6 +542,20 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.0f;
   float m_run = kNeg, l_run = 0.0f;
+  char* qimg = smem + 2 * kBuf + wave * (32 * PITCH);
+  if (p.q_lds) {
+    const char* qb = p.q + ((int64_t)b * p.q_bs + (int64_t)h * D) * 2;
+    const int lastc = (D * 2 + 15) / 16 - 1;
+    for (int pc = kpar; pc < CH / 2; pc += KS2) {
+      const int idx = pc * 64 + lane;
+      const int r = idx / CH, pch = idx - r * CH;
+      int lc = pch ^ swk(r);
+      lc = lc < lastc ? lc : lastc;
+      int row = qt * 32 + r;
+      row = row < p.Sq ? row : p.Sq - 1;                            // rows past the end: a valid row, never stored
+      glds16(qb + (int64_t)row * p.q_rs * 2 + lc * 16, qimg + (idx - lane) * 16);
+    }
+  }
 
   // ---- window DMA: 2 x kPieces pieces of 1 KiB per window (K image, then V image); piece pc is issued by wave pc % nwv -------------
   const int last_chunk = (D * 2 + 15) / 16 - 1;
@@ -537,12 +574,29 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
   };
   const int n_win = (kv_block_end + W - 1) / W;
   if (n_win > 0) issue_window(0, 0);
+  ATTN_STAMP(1);
   for (int w = 0; w < n_win; ++w) {
     const int win0 = w * W;
     const int n_tiles = (min(W, kv_block_end - win0) + 31) >> 5;
+#ifdef STLLM_ATTN_TRACE
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of window w landed ...
     __syncthreads();                                    // ... everybody's did, and everybody is done with window w - 1
+#ifdef STLLM_ATTN_TRACE
+    t_wait += __builtin_amdgcn_s_memtime() - tw0;
+    if (w == 0) ATTN_STAMP(2);
+#endif
     if (w + 1 < n_win) issue_window(win0 + W, (w + 1) & 1);
+    if (p.q_lds && w == 0) {   // (every piece of the tile landed before the barrier above: each wave drained its own queue first)
+      const char* qa = qimg + li * PITCH;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const i32x4 z = {0, 0, 0, 0};
+        const i32x4 f = *reinterpret_cast<const i32x4*>(qa + (((ks * 2 + lh) ^ swk(li)) << 4));
+        qf[ks] = (ks * 16 + lh * 8 < D) ? f : z;                      // dims past D: K's chunk there is a copy of the last real one
+      }
+    }
     if (q_live) {
       const char* kimg = smem + (w & 1) * kBuf;
       const char* vimg = kimg + kImg;
@@ -619,32 +673,50 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
       }
     }
   }
+  ATTN_STAMP(3);
+  ATTN_STAMP_VAL(6, n_win);
+  ATTN_STAMP_VAL(7, t_wait);
   if constexpr (KS2 > 1) {
+    // merge of the KS2 partial (m, l, O) states of a query tile.  p.merge_par (launch_dma: (KS2 - 1) x nwaves parked states fit in the LDS): every
+    // partner parks its state in its OWN slot, ONE barrier pair, the tile's first wave folds them in the fixed order 1, 2, .. (bit-identical to the
+    // sequential rounds below, which cost two barriers per partner: 5.4 k cycles at KS2 = 4 in the timeline, profiles/r06_attn_trace.md)
     float* mbuf = reinterpret_cast<float*>(smem);
-    for (int pp = 1; pp < KS2; ++pp) {
+    constexpr int kState = DB * 16 + 2;
+    auto fold = [&](int slot) {
+      const float m1 = mbuf[((slot * kState + DB * 16) << 6) + lane];
+      const float l1 = mbuf[((slot * kState + DB * 16 + 1) << 6) + lane];
+      const float m = fmaxf(m_run, m1);
+      const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.scale_log2), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.scale_log2);
+      l_run = l_run * a0 + l1 * a1;
+      m_run = m;
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + mbuf[((slot * kState + i * 16 + r) << 6) + lane] * a1;
+    };
+    auto park = [&](int slot) {
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mbuf[((slot * kState + i * 16 + r) << 6) + lane] = o[i][r];
+      mbuf[((slot * kState + DB * 16) << 6) + lane] = m_run;
+      mbuf[((slot * kState + DB * 16 + 1) << 6) + lane] = l_run;
+    };
+    if (p.merge_par) {
       __syncthreads();
-      if (kpar == pp) {
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] = o[i][r];
-        mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane] = m_run;
-        mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane] = l_run;
-      }
+      if (kpar > 0) park((kpar - 1) * nwaves + wave);
       __syncthreads();
-      if (kpar == 0) {
-        const float m1 = mbuf[((wave * (DB * 16 + 2) + DB * 16) << 6) + lane];
-        const float l1 = mbuf[((wave * (DB * 16 + 2) + DB * 16 + 1) << 6) + lane];
-        const float m = fmaxf(m_run, m1);
-        const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.scale_log2), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.scale_log2);
-        l_run = l_run * a0 + l1 * a1;
-        m_run = m;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * a0 + mbuf[((wave * (DB * 16 + 2) + i * 16 + r) << 6) + lane] * a1;
+      if (kpar == 0)
+        for (int pp = 1; pp < KS2; ++pp) fold((pp - 1) * nwaves + wave);
+    } else {
+      for (int pp = 1; pp < KS2; ++pp) {
+        __syncthreads();
+        if (kpar == pp) park(wave);
+        __syncthreads();
+        if (kpar == 0) fold(wave);
       }
     }
+    ATTN_STAMP(4);
     if (kpar != 0) return;
   }
   if (q_live && qrow < p.Sq) {
@@ -664,6 +736,7 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
       }
     }
   }
+  ATTN_STAMP(5);
 }
 
 // ---- D = 88 (EVA ViT: 257 keys, padded to 96 dims x 288 keys): the same staging for the resident-K/V kernel -------------------------
@@ -675,6 +748,7 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
 // V needs no swizzle for the transposing reads (four consecutive rows = four disjoint 16-bank spans).
 template <typename T>
 __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
+  ATTN_STAMP(0);
   constexpr int DP = 96, KS = DP / 16, DB = DP / 32, PITCH = 192, ROWS = 288;
   constexpr int kImg = ROWS * PITCH;                 // 55 296 bytes = 54 pieces of 1 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -717,6 +791,7 @@ __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
   asm volatile("" ::: "memory");   // the Q loads are OLDER than the window DMAs: the first counted wait below covers them
   const int n_win = (min(kvlen, ROWS) + 95) / 96;
   for (int w = 0; w < n_win; ++w) issue_window(w);
+  ATTN_STAMP(1);
   f32x16 o[DB];
 #pragma unroll
   for (int i = 0; i < DB; ++i)
@@ -736,6 +811,7 @@ __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
     else if (nwaves == 9 && later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // ... and everybody else's
+    ATTN_STAMP(2 + 2 * (w < 2 ? w : 2));
     if (!q_live) continue;
     const int t_hi = min(n_tiles, 3 * (w + 1));
     for (int t = 3 * w; t < t_hi; ++t) {
@@ -805,6 +881,7 @@ __global__ __launch_bounds__(768) void attn_dma88_kernel(const AttnParams p) {
         }
       }
     }
+    ATTN_STAMP(3 + 2 * (w < 2 ? w : 2));
   }
   if (q_live && qrow < p.Sq) {
     const float inv = 1.0f / l_run;
@@ -848,22 +925,29 @@ int launch_dma88(const AttnParams& p, hipStream_t stream) {
 template <typename T, int KS2, int DP = 128>
 int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
   constexpr int W = DP == 128 ? 128 : 96;
-  constexpr int lds = 2 * 2 * W * (DP * 2);   // two buffers of [K | V] windows (128 KiB at 128 dims, 72 KiB at 96: two workgroups per CU)
+  constexpr int lds_win = 2 * 2 * W * (DP * 2);   // two buffers of [K | V] windows (128 KiB at 128 dims, 72 KiB at 96: two workgroups per CU)
+  constexpr int lds_max = DP == 128 ? 160 * 1024 : 80 * 1024;
   static StllmPerDevice attr_dev;   // the dynamic-LDS opt-in is a per-device attribute
   bool attr_first;
   const int attr_d = attr_dev.enter(&attr_first);
   if (attr_first) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     attr_dev.done(attr_d);
   }
   const int q_tiles = (p.Sq + 31) / 32;
   int nw = nw_req < q_tiles ? nw_req : q_tiles;
-  if (KS2 > 1 && nw * (DP / 32 * 16 + 2) * 256 > lds) {
+  if (KS2 > 1 && nw * (DP / 32 * 16 + 2) * 256 > lds_win) {
     stllm_set_error("stllm_attention(dma): key-split merge buffer does not fit (nw=%d)", nw);
     return STLLM_ERR_UNSUPPORTED;
   }
+  // query tiles through the LDS (attn_dma_kernel) when their images fit behind the window buffers; option attn_q_lds = 0: never (A/B)
+  AttnParams pp = p;
+  const int q_img = nw * 32 * (DP * 2);
+  pp.q_lds = (stllm_options().attn_q_lds != 0 && lds_win + q_img <= lds_max && ((int64_t)p.q_rs * 2) % 16 == 0 && (p.D * 2) % 16 == 0) ? 1 : 0;
+  const int lds = lds_win + (pp.q_lds ? q_img : 0);
+  pp.merge_par = (KS2 > 1 && stllm_options().attn_q_lds != 0 && (KS2 - 1) * nw * (DP / 32 * 16 + 2) * 256 <= lds) ? 1 : 0;
   dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw * KS2);
-  hipLaunchKernelGGL((attn_dma_kernel<T, KS2, DP>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((attn_dma_kernel<T, KS2, DP>), grid, block, lds, stream, pp);
   STLLM_CHECK_LAUNCH("stllm_attention(dma)");
   return STLLM_OK;
 }
@@ -1416,3 +1500,16 @@ extern "C" int stllm_attention_decode(int dtype, const void* q, int64_t q_bs, co
   STLLM_CHECK_LAUNCH("stllm_attention_decode");
   return STLLM_OK;
 }
+
+#ifdef STLLM_ATTN_TRACE
+// trace build only: the stamps of the last launch(es) -> host (tools/attn_trace.py)
+extern "C" int stllm_attn_trace_read(void* dst, int64_t bytes, int clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_trace), (size_t)bytes) != hipSuccess) return -2;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_attn_trace)) != hipSuccess || hipMemset(p, 0, sizeof(g_attn_trace)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
