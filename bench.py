@@ -139,7 +139,7 @@ def algorithmic_flops(T, S, Lt=0, S_unmasked=0, btadapter=False):
 
 def cpu_baseline(T, S, budget_s=25.0):
     """The oracle (a port of the reference's CPU path, oracle/stllm_oracle.py) timed on this box's host cores
-    on a BOUNDED sample of the same workload, extrapolated per stage (reported, never the target)."""
+    on ONE whole clip of the same workload (reported, never the target)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import shapes
     import stllm_oracle as O
@@ -157,30 +157,48 @@ def cpu_baseline(T, S, budget_s=25.0):
             t0 = time.perf_counter(); O.vit_forward(frp, sdp, "v."); probe[n] = time.perf_counter() - t0
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    NF, VB, QL, LL = 16, 8, 12, 8    # sample: 16 frames x 8/39 ViT blocks, 16 frames x 12/12 Q-Former layers, 8/32 Llama layers (~10-20 s of CPU work)
+    # the FULL stack is run once — 16 frames through 39 ViT blocks and 12 Q-Former layers, the S-token sequence through 32 decoder layers
+    # and lm_head — instead of a slice multiplied up.  Only the WEIGHT TENSORS are bounded: 8 distinct blocks / layers of random values, block i of the run
+    # uses set i % 8 (6.5 GB of decoder weights instead of 26 GB of host memory; still far beyond any cache, so every pass streams its weights from DRAM
+    # like distinct ones would).
+    NF, VB, QL, LL, WSETS = T, 39, 12, 32, 8
+    import re
+
+    def rnd_cycled(shp, pat):
+        """random tensors for the shape table; keys whose block / layer index (regex group 1 of `pat`) is >= WSETS alias the tensors of index % WSETS"""
+        out = {}
+        for k, v in shp.items():
+            m = re.search(pat, k)
+            if m and int(m.group(1)) >= WSETS:
+                continue
+            out[k] = torch.randn(v) * 0.02
+        for k in shp:
+            m = re.search(pat, k)
+            if m and int(m.group(1)) >= WSETS:
+                out[k] = out[k[:m.start(1)] + str(int(m.group(1)) % WSETS) + k[m.end(1):]]
+        return out
+
     with torch.no_grad():
-        sd = rnd(shapes.vit_shapes(VB, "v."))
+        sd = rnd_cycled(shapes.vit_shapes(VB, "v."), r"blocks\.(\d+)\.")
         fr = torch.randn(NF, 3, 224, 224)
-        O.vit_forward(fr[:2], sd, "v.")  # warm-up (thread pool, allocator)
-        t0 = time.perf_counter(); O.vit_forward(fr, sd, "v."); t_vit2 = time.perf_counter() - t0
-        vit_per_frame = t_vit2 / NF / VB * 39
+        O.vit_forward(fr[:1], {k: v for k, v in sd.items()}, "v.")  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter(); O.vit_forward(fr, sd, "v."); t_vit = time.perf_counter() - t0
         sd = rnd({**shapes.qformer_shapes(QL, False, p="q."), "qt": (1, 32, 768)})
         enc = torch.randn(NF, 257, 1408)
         O.qformer_forward(sd["qt"].expand(2, -1, -1), enc[:2], sd, "q.")
         t0 = time.perf_counter(); O.qformer_forward(sd["qt"].expand(NF, -1, -1), enc, sd, "q."); t_qf = time.perf_counter() - t0
-        qf_per_frame = t_qf / NF / QL * 12
-        sd = rnd({k: v for k, v in shapes.llama_shapes(LL).items() if "embed" not in k})
+        sd = rnd_cycled({k: v for k, v in shapes.llama_shapes(LL).items() if "embed" not in k}, r"layers\.(\d+)\.")
         x = torch.randn(1, S, 4096) * 0.05
-        O.llama_forward(x[:, :64], None, sd)
-        t0 = time.perf_counter(); h = O.llama_forward(x, None, sd); t_l1 = (time.perf_counter() - t0) / LL
+        O.llama_forward(x[:, :16], None, sd)
+        t0 = time.perf_counter(); h = O.llama_forward(x, None, sd); t_llm = time.perf_counter() - t0
         t0 = time.perf_counter(); O.lm_logits(h, sd); t_head = time.perf_counter() - t0
-    clip_s = T * (vit_per_frame + qf_per_frame) + 32 * t_l1 + t_head
+    clip_s = t_vit + t_qf + t_llm + t_head
     return {"value": round(T * 32 / clip_s, 3), "unit": "video-tokens/s", "cores": cores, "kind": "port",
             "dtype": "f32", "host_threads_available": ncpu,
             "thread_probe_s": {str(n): round(t, 3) for n, t in sorted(probe.items())},   # ViT 4 frames x 2 blocks at each thread count: `cores` is the fastest
-            "sample": f"oracle on CPU fp32, {cores} threads: ViT {NF} frames x {VB}/39 blocks ({t_vit2:.2f}s), Q-Former {NF} frames x "
-                      f"{QL}/12 layers ({t_qf:.2f}s), Llama {LL}/32 layers at S={S} ({t_l1 * LL:.2f}s) + lm_head ({t_head:.2f}s); "
-                      f"extrapolated linearly to T={T}, 39/12/32 layers => {clip_s:.1f} s/clip"}
+            "sample": f"oracle on CPU fp32, {cores} threads, ONE whole clip measured (nothing extrapolated): ViT {NF} frames x {VB} blocks ({t_vit:.2f}s), "
+                      f"Q-Former {NF} frames x {QL} layers ({t_qf:.2f}s), Llama {LL} layers at S={S} ({t_llm:.2f}s) + lm_head ({t_head:.2f}s) "
+                      f"=> {clip_s:.1f} s/clip; weight tensors: {WSETS} distinct random blocks / layers cycled (host memory), every pass streams from DRAM"}
 
 
 def parity_vs_fixture(logits, loss, name="c2_full", mask=None):

@@ -540,7 +540,7 @@ def mvm_loss(mask_hidden: Tensor, unmask_hidden: Tensor, mask: Tensor, img_start
 def stllm_forward(samples: dict, sd: SD, cfg: dict):
     """samples: {"image": [B,T,3,224,224], "before_ids","after_ids","answer_ids": list[list[int]],
     optional "qformer_ids"/"qformer_mask": [B,Lt], optional "mask": [B,L] bool (injected, True = dropped)}.
-    cfg: vit_model, video_input, residual_size, use_mask, mvm_decode, qformer_text_input, has_qformer, pad_id, bos_id, n_heads.
+    cfg: vit_model, video_input, residual_size, use_mask, mvm_decode, qformer_text_input, has_qformer, pre_encoding, pad_id, bos_id, n_heads.
     Returns dict(logits, loss, loss_mvm, inputs_embeds, attention_mask, targets)."""
     p = "model.stllm_model."
     image = samples["image"]
@@ -549,7 +549,11 @@ def stllm_forward(samples: dict, sd: SD, cfg: dict):
     if cfg.get("qformer_text_input", False):
         tids = samples["qformer_ids"].repeat_interleave(T, dim=0)
         tmask = samples["qformer_mask"].repeat_interleave(T, dim=0)
-    emb = encode_img(image, sd, p, cfg.get("vit_model", "eva_clip_g"), tids, tmask, has_qformer=cfg.get("has_qformer", True))
+    if cfg.get("pre_encoding", False):
+        # st_llm.py:452-455: `image` holds pre-extracted features [B, T, L, C]; only llama_proj runs (use_image stays False whatever T is)
+        emb = F.linear(image.float(), sd[p + "llama_proj.weight"], sd[p + "llama_proj.bias"])
+    else:
+        emb = encode_img(image, sd, p, cfg.get("vit_model", "eva_clip_g"), tids, tmask, has_qformer=cfg.get("has_qformer", True))
     emb = video_pool(emb, cfg.get("video_input"), sd, p, cfg.get("residual_size", 4))
     un = None
     mask = None

@@ -217,10 +217,31 @@ def h2d(t, device):
     dev = torch.device(device)
     if dev.type != "cuda" or t.is_cuda:
         return t.to(dev)
+    t = t.contiguous()
+    # content-keyed cache of small tables (round 6): the index tables / labels / lengths of a step are functions of shapes and token
+    # ids only — identical every step of a bench loop and every frame batch of a served prompt — so steady state issues NO host -> device copy at all.
+    # The cached device tensors are shared between calls: READ-ONLY for every consumer (all of them are gather / label / length operands).
+    key = None
+    nbytes = t.numel() * t.element_size()
+    if _H2D_CACHE_ON and 0 < nbytes <= _PinnedRing.SLOT_BYTES and t.dtype in (torch.int32, torch.int64, torch.bool, torch.uint8):
+        raw = t.numpy().tobytes()
+        key = (_dev_index(dev), int(torch.cuda.current_stream(dev).cuda_stream), t.dtype, tuple(t.shape), hash(raw), len(raw))
+        hit = _h2d_cache.get(key)
+        if hit is not None and hit[0] == raw:
+            return hit[1]
     if _pinned_ring is None:
         _pinned_ring = _PinnedRing()
-    out = _pinned_ring.stage(t.contiguous(), dev)
-    return out if out is not None else t.to(dev)
+    out = _pinned_ring.stage(t, dev)
+    out = out if out is not None else t.to(dev)
+    if key is not None:
+        if len(_h2d_cache) >= 512:
+            _h2d_cache.clear()
+        _h2d_cache[key] = (raw, out)
+    return out
+
+
+_H2D_CACHE_ON = os.environ.get("STLLM_H2D_CACHE", "1") != "0"
+_h2d_cache = {}
 
 
 _const_tables = {}

@@ -64,8 +64,6 @@ class STLLMModel(Blip2Base):
                  use_grad_checkpoint=False, vit_precision="fp16", freeze_vit=True, has_qformer=True,
                  freeze_qformer=True, num_query_token=32, llama_model="", max_txt_len=32, end_sym="\n", device=None):
         super().__init__()
-        if pre_encoding:
-            raise NotImplementedError("the pre_encoding path is unused by every shipped config")
         self.tokenizer = self.init_tokenizer(truncation_side="left")
         self.pre_encoding, self.video_input, self.use_mask = pre_encoding, video_input, use_mask
         self.mvm_decode, self.qformer_text_input, self.residual_size = mvm_decode, qformer_text_input, residual_size
@@ -296,6 +294,10 @@ class STLLMModel(Blip2Base):
         w, b = self.llama_proj.packed(dt)
         return hip.gemm(a, w, dtype=dt, bias=b, out_f32=True, M=n * 64, a_rows=(64, 257 * C)).view(n, 64, 4096)
 
+    def _project_features(self, feats):
+        """st_llm.py:452-454 (pre_encoding): llama_proj on pre-extracted features [B, T, L, C] -> [B, T, L, 4096] fp32 — one GEMM with the bias fused."""
+        return self.llama_proj(feats)
+
     def _encode_frames(self, frames, text_per_frame, T, dt):
         """ViT -> ln_vision -> Q-Former -> projector for a flat list of frames -> [n,32,4096] fp32."""
         n = frames.shape[0]
@@ -412,6 +414,12 @@ class STLLMModel(Blip2Base):
             qtext = None
         clip_sharded = False
         self._sp_state = None
+        pre = bool(self.pre_encoding)
+        if pre:   # st_llm.py:452-455: `image` = pre-extracted features [B, T, L, C]; only llama_proj runs
+            if image.dim() != 4 or image.shape[-1] != self.llama_proj.weight.shape[1]:
+                raise ValueError(f"pre_encoding: samples['image'] must hold features [B, T, L, {self.llama_proj.weight.shape[1]}], got {tuple(image.shape)}")
+            if self.frame_parallel is not None:
+                raise NotImplementedError("pre_encoding: nothing is encoded, so there are no frames to share between ranks — shard the clips at the caller")
         if self.frame_parallel is not None and self.vit_model != "eva_clip_g" and image.dim() == 5:
             # BT-Adapter: clip-parallel from the first kernel on — this rank's clips only, then the single-GPU path
             from .. import parallel
@@ -437,8 +445,8 @@ class STLLMModel(Blip2Base):
         # (a single request, the first step after a synchronisation, a profiler-slowed host: 0.9-1.2 ms, profiles/r05_bench_gaps.md).
         dev = image.device
         T = image.shape[1]
-        use_image = bool(T == 1 or image.dim() == 4)        # encode_img's rule (st_llm.py:326-328)
-        Lq = self.tokens_per_frame
+        use_image = bool(T == 1 or image.dim() == 4) and not pre   # encode_img's rule (st_llm.py:326-328); pre_encoding never sets it (st_llm.py:451)
+        Lq = image.shape[2] if pre else self.tokens_per_frame
         if use_image:
             L = Lq
         elif self.video_input == "all":
@@ -472,7 +480,10 @@ class STLLMModel(Blip2Base):
                     samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
                 B = len(own)
         # ---- device work, part 1: the encode (+ the team's token exchange) goes out now; the host runs ahead of it ----------------
-        img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
+        if pre:
+            img_embeds, use_image_enc = self._project_features(image), False
+        else:
+            img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
         assert use_image_enc == use_image
         if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
             return None

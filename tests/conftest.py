@@ -28,3 +28,15 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory():
+    """GPU box only: a full-size model (35 GB of fp32 parameters + 25 GB of packed copies) sits in reference cycles (module <-> cached closures) that only
+    the cyclic collector frees, and that collector is paced by Python allocations, not by device memory: five full-size tests in a row ran the 288 GB out."""
+    yield
+    import torch
+    if torch.cuda.is_available():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()

@@ -269,6 +269,26 @@ def fx_stllm_no_qformer():
                                       max_txt_len=32, end_sym=" 2", vit_precision="fp32"), Tn=2)
 
 
+def fx_stllm_pre_encoding():
+    """st_llm.py:452-455: pre_encoding=True — samples["image"] holds pre-extracted Q-Former features [B, T, 32, 768]; forward() applies llama_proj only
+    (the vision tower and the Q-Former are built but never run), 'all' pooling over T = 3 frames.  No shipped yaml sets it: pinned here."""
+    cfg = _Cfg(dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, llama_model="", video_input="all", use_mask=False, mvm_decode=False,
+                    qformer_text_input=False, pre_encoding=True, max_txt_len=32, end_sym=" 2", vit_precision="fp32"))
+    model = fill_stllm(_build_ref_stllm(cfg, 1, 1, 2))
+    samples, meta = _samples(2, 3, False)
+    samples["image"] = T("input.features", (2, 3, 32, 768), 0.5)
+    sm = model.model.stllm_model
+    assert sm.pre_encoding
+    out = model(samples=samples)
+    ie, am, ue, ua, tg = sm(samples)
+    o2, _, _ = model.model(samples)
+    save("stllm_pre_encoding",
+         before=_ragged(meta["before"]), after=_ragged(meta["after"]), answer=_ragged([a + [2] for a in meta["answer"]]), qtext=_ragged(meta["qtext"]),
+         inputs_embeds=sub(ie, 1, 1, 16), inputs_embeds_stats=stats(ie), attention_mask=am.numpy(), targets=tg.numpy(),
+         hidden=sub(o2[0], 1, 1, 16), hidden_stats=stats(o2[0]),
+         logits=sub(out.logits, 1, 1, 61), logits_stats=stats(out.logits), loss=np.array([out.loss.item(), -1.0]))
+
+
 def fx_stllm_instructblip():
     fx_stllm("stllm_instructblip", dict(vit_model="eva_clip_g", image_size=224, num_query_token=32,
                                         llama_model="", video_input="residual", residual_size=4,
@@ -578,7 +598,7 @@ def fx_full(tag):
 
 
 ALL = dict(vit_ops=fx_vit_ops, qformer=fx_qformer, pooling=fx_pooling, llama=fx_llama,
-           stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip, stllm_no_qformer=fx_stllm_no_qformer,
+           stllm_minigpt4=fx_stllm_minigpt4, stllm_instructblip=fx_stllm_instructblip, stllm_no_qformer=fx_stllm_no_qformer, stllm_pre_encoding=fx_stllm_pre_encoding,
            stllm_flagship=fx_stllm_flagship, btadapter=fx_btadapter, chat=fx_chat, generate=fx_generate, backward=fx_backward, pos_embed=fx_pos_embed)
 SLOW = dict(c1_full=fx_c1_full, c2_full=fx_c2_full, c3_full=lambda: fx_full("c3"), c4_full=lambda: fx_full("c4"), c5_full=lambda: fx_full("c5"))
 

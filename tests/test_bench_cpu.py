@@ -12,8 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--dry-cpu", "--steps", "1", "--warmup", "0", "--vit-depth", "1", "--qformer-layers", "2", "--llm-layers", "1", "--frames", "2"]
 
 
-def _run(extra, timeout=900):
+def _run(extra, timeout=900, threads=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if threads:   # many ranks on few cores: one BLAS thread per rank (8 ranks x 8 threads on 8 vCPUs spend their time in the scheduler)
+        env.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -49,6 +51,23 @@ def test_bench_self_spawns_two_ranks(config, scaling, batch):
         assert fp["token_exchange_bytes_sent_per_rank"] == [32 * 4096 * 4] * 2
         oo = fp["owner_only_throughput_plan"]     # the same batch with the owner prefilling alone (helpers return before pooling): timed next to the default
         assert oo["ms_per_step"] > 0 and oo["latency_ms"] > 0 and oo["clips_per_rank"] == [1, 0] and sum(oo["frames_per_rank"]) == 2
+
+
+def test_bench_self_spawns_eight_ranks_clip_teams_of_two():
+    """VERDICT r05 #8c: the N = 8 plan of the driver's `bench.py --gpus 8` — c3's 4 clips as 4 teams of 2 ranks, point-to-point token exchange,
+    sequence-parallel prefill inside every team, the loss run along the team — executed end to end by 8 gloo processes (contract backend, reduced depth:
+    plumbing, not a measurement; no byte has crossed RCCL for this repository yet)."""
+    res = _run(["--gpus", "8", "--config", "c2"], timeout=1500, threads=1)
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["config"]["global_batch"] == 8 and res["value"] > 0
+    assert res["plan"]["teams"] == [[r] for r in range(8)] and res["token_exchange_in_step"] is False     # c2 weak scaling: one clip per rank, nothing on the wire
+    fp = res["frame_parallel"]
+    assert fp["config"] == "c3" and fp["scaling"] == "strong" and fp["sequence_parallel_prefill"] is True and fp["token_exchange_in_step"] is True
+    assert fp["plan"]["teams"] == [[0, 4], [1, 5], [2, 6], [3, 7]] and all(fp["plan"]["sp"])
+    assert fp["plan"]["frames"] == [[[0, 1], [1, 2]]] * 4 and fp["frames_per_rank"] == [1] * 8 and fp["clips_per_rank"] == [1] * 8
+    assert fp["received_blocks_bit_identical"] is True and fp["received_blocks_max_abs_diff"] == 0.0
+    assert fp["ms_per_step"] > 0 and fp["latency_ms"] > 0 and fp["ms_per_step_1gpu"] > 0
+    oo = fp["owner_only_throughput_plan"]
+    assert sum(oo["frames_per_rank"]) == 8 and sum(oo["clips_per_rank"]) == 4
 
 
 def test_bench_single_rank_line_carries_projection_blocks_and_telemetry_keys():

@@ -101,6 +101,30 @@ def test_host_graph_matches_oracle(name):
     assert abs(out.loss.item() - ref["loss"].item()) <= 1e-4
 
 
+def test_pre_encoding_host_graph_matches_oracle():
+    """st_llm.py:452-455 (pre_encoding=True): samples["image"] holds features [B, T, 32, 768] — forward() projects them, pools, assembles; against the
+    oracle's branch (which tests/test_oracle_vs_golden.py pins to the reference's own forward)."""
+    from stllm_amd import runtime
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False, mvm_decode=False,
+               qformer_text_input=False, pre_encoding=True, max_txt_len=32, end_sym=" 2")
+    model = build(cfg)
+    assert model.model.stllm_model.pre_encoding
+    samples, osamples = make_inputs(2, 3, False)
+    feats = T("input.features", (2, 3, 32, 768), 0.5)
+    samples["image"], osamples["image"] = feats, feats
+    sd = sd_from({**shapes.stllm_model_shapes(1, 2, False, "all", False, qf_vocab=32000), **shapes.llama_shapes(1)})
+    ref = O.stllm_forward(osamples, sd, dict(cfg, pad_id=0, bos_id=1))
+    with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+        out = model(samples=samples)
+    scale = ref["logits"].abs().max().item()
+    assert out.logits.shape == ref["logits"].shape
+    assert (out.logits - ref["logits"]).abs().max().item() <= 5e-5 * scale
+    assert abs(out.loss.item() - ref["loss"].item()) <= 1e-4
+    with pytest.raises(ValueError):   # frames instead of features
+        with _cpu_backend.installed(), runtime.use_dtype("fp32"):
+            model(samples=dict(samples, image=T("input.video", (2, 3, 3, 224, 224))))
+
+
 def test_chat_path_on_host_graph():
     from stllm_amd import runtime
     from stllm_amd.conversation import Chat

@@ -125,6 +125,33 @@ E2E = [("stllm_minigpt4", dict(vit_model="eva_clip_g", image_size=224, num_query
 
 
 @pytest.mark.parametrize("mode,tol", MODES)
+def test_stllm_pre_encoding_vs_golden(mode, tol):
+    """st_llm.py:452-455 (pre_encoding=True): features [B, T, 32, 768] -> llama_proj -> 'all' pooling -> prefill, against the reference's own forward
+    (tests/golden/stllm_pre_encoding.npz)."""
+    from stllm_amd import runtime
+    g = golden("stllm_pre_encoding")
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False, mvm_decode=False,
+               qformer_text_input=False, pre_encoding=True, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg)
+    samples = _samples_from_fixture(g, 3, False)
+    samples["image"] = T("input.features", (2, 3, 32, 768), 0.5).cuda()
+    sm = model.model.stllm_model
+    with runtime.use_dtype(mode):
+        ie, am, ue, ua, tg = sm(samples)
+        out = model(samples=samples)
+    assert np.array_equal(am.cpu().numpy(), g["attention_mask"])
+    assert np.array_equal(tg.cpu().numpy(), g["targets"])
+    assert rel_err(sub(ie, 1, 1, 16), g["inputs_embeds"]) <= tol, "inputs_embeds"
+    valid = g["attention_mask"].astype(bool)
+    lg = out.logits.cpu().numpy()[:, :, ::61]
+    err_abs = float(np.abs(lg[valid] - g["logits"][valid]).max())
+    scale = float(np.abs(g["logits"]).max())
+    print(f"\n[stllm_pre_encoding {mode}] logits max-abs err {err_abs:.3e} (abs-max {scale:.2f}); loss {out.loss.item():.5f} vs {g['loss'][0]:.5f}")
+    assert err_abs <= tol * scale
+    assert abs(out.loss.item() - g["loss"][0]) <= max(tol, 2e-4) * max(1.0, abs(g["loss"][0]))
+
+
+@pytest.mark.parametrize("mode,tol", MODES)
 @pytest.mark.parametrize("name,cfg,Tn,text", E2E, ids=[e[0] for e in E2E])
 def test_stllm_forward_vs_golden(name, cfg, Tn, text, mode, tol):
     """STLLMForCausalLM.forward(samples) — the reference's training-style entry point (st_llm.py:116-146)."""

@@ -117,7 +117,8 @@ def _e2e(name, cfg, Tn, text):
     sdshape = {**shapes.stllm_model_shapes(2, 2, text, cfg["video_input"], cfg.get("mvm_decode", False), qf_vocab=32000,
                                            has_qformer=cfg.get("has_qformer", True)), **shapes.llama_shapes(2)}
     sd = sd_from(sdshape)
-    samples = {"image": T("input.video", (2, Tn, 3, 224, 224)), "before_ids": unragged(g["before"]),
+    image = T("input.features", (2, Tn, 32, 768), 0.5) if cfg.get("pre_encoding") else T("input.video", (2, Tn, 3, 224, 224))
+    samples = {"image": image, "before_ids": unragged(g["before"]),
                "after_ids": unragged(g["after"]), "answer_ids": unragged(g["answer"])}
     if text:
         # the reference's BERT tokenizer call uses add_special_tokens=True (st_llm.py:344): the fixture's
@@ -163,6 +164,13 @@ def test_stllm_without_qformer():
     oracle's branch against the reference's own forward."""
     _e2e("stllm_no_qformer", dict(vit_model="eva_clip_g", video_input="mean", use_mask=False, mvm_decode=False, qformer_text_input=False,
                                   has_qformer=False), 2, False)
+
+
+def test_stllm_pre_encoding():
+    """st_llm.py:452-455 (pre_encoding=True): samples["image"] = pre-extracted features [B, T, 32, 768], llama_proj only — the oracle's branch against
+    the reference's own forward."""
+    _e2e("stllm_pre_encoding", dict(vit_model="eva_clip_g", video_input="all", use_mask=False, mvm_decode=False, qformer_text_input=False,
+                                    pre_encoding=True), 3, False)
 
 
 CFG_FLAGSHIP = dict(vit_model="eva_clip_g", video_input="residual", residual_size=4, use_mask=True, mvm_decode=True, qformer_text_input=True)
