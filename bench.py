@@ -53,7 +53,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "mixed": 2500.0}  # dense TFLOP/s, MI355X_MICROARCH.md (bf16x3: bf16 MFMAs, 3x the algorithmic FLOPs)
-ROUND = 5   # profiles/traffic_r{ROUND:02d}.json is the HBM-traffic measurement that belongs to this round's kernels
+ROUND = 6   # profiles/traffic_r{ROUND:02d}.json is the HBM-traffic measurement that belongs to this round's kernels
 
 CONFIGS = {
     "c2": dict(clips=None, frames=16, scaling="weak",

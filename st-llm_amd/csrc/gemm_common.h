@@ -35,7 +35,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + k;
 }
 
-constexpr int kGroupM = 8;  // tile rows per L2 locality group
+#ifndef STLLM_GROUP_M
+#define STLLM_GROUP_M 8   // (experiment builds: -DSTLLM_GROUP_M=4, profiles/r06_group_m.md)
+#endif
+constexpr int kGroupM = STLLM_GROUP_M;  // tile rows per L2 locality group
 
 // work id -> (tm, tn): groups of kGroupM tile rows, tm fastest inside a group.  With the XCD remap
 // applied to the PERSISTENT block id, the 64 tiles an XCD runs concurrently form an ~8x8 patch that

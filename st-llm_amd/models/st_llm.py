@@ -303,6 +303,9 @@ class STLLMModel(Blip2Base):
         n = frames.shape[0]
         feats = self.visual_encoder.forward_features_flat(frames)
         enc16, _ = hip.layernorm(feats, self.ln_vision.weight, self.ln_vision.bias, self.ln_vision.eps, dtype=dt)
+        hook = getattr(self, "_after_vit_hook", None)
+        if hook is not None:   # forward(): the host-side plan is built here, under the ViT's kernels
+            hook()
         if not self.has_qformer:
             return self._project_patches(enc16, n, dt)
         ids = tmask = None
@@ -480,15 +483,11 @@ class STLLMModel(Blip2Base):
                     samples = dict(samples, mask=torch.as_tensor(samples["mask"])[own])
                 B = len(own)
         # ---- device work, part 1: the encode (+ the team's token exchange) goes out now; the host runs ahead of it ----------------
-        if pre:
-            img_embeds, use_image_enc = self._project_features(image), False
-        else:
-            img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
-        assert use_image_enc == use_image
-        if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
-            return None
-        plan = None
-        if own is None or own:
+        # The plan (tokenizers, _assemble, index tables: Python) is built by a hook that _encode_frames calls right after the ViT + ln_vision have been
+        # enqueued and BEFORE the Q-Former's ~100 short launches (round 6): the GPU is busy with >= 10 ms of ViT kernels then.  Behind the whole encode
+        # (round 5) it was free only while the host kept a lead through the Q-Former's 5-18 us kernels — which a profiler-slowed host does not: 0.3-0.57 ms
+        # of idle GPU in front of gather_rows under rocprofv3 (profiles/r06_bench_gaps.md).
+        def build_plan():
             kept = [list(range(L)) for _ in range(B)]
             mask = None
             if not use_image and self.use_mask:
@@ -513,6 +512,27 @@ class STLLMModel(Blip2Base):
             if mask is not None:
                 urows, un_a, _ = self._assemble(L, [list(range(L))] * B, instruction, answers, B)
                 plan.update(urows=self._upload_rows(urows, dev), un_a=hip.with_host(un_a, dev))
+            return plan
+
+        plan_box = []
+
+        def after_vit():
+            if not plan_box and (own is None or own):
+                plan_box.append(build_plan())
+
+        self._after_vit_hook = after_vit
+        try:
+            if pre:
+                img_embeds, use_image_enc = self._project_features(image), False
+            else:
+                img_embeds, atts_img, use_image_enc = self.encode_img(image, qtext)
+        finally:
+            self._after_vit_hook = None
+        assert use_image_enc == use_image
+        if own is not None and not own:     # this rank only encoded (and sent) frames: no clip of the batch is prefilled here
+            return None
+        after_vit()                          # (paths that never reach _encode_frames: pre_encoding, the BT-Adapter backbone)
+        plan = plan_box[0] if plan_box else None
         # ---- device work, part 2: pooling -> ONE gather per sequence block ------------------------------------------------------------
         if not use_image:
             img_embeds = self.pool_video(img_embeds)

@@ -21,7 +21,8 @@ for _ in range(iters):
     elif epi == "rope":
         from stllm_amd import pack
         cos, sin = pack.rope_tables(M, device="cuda")
-        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=M, rope_cols=(N // 3) * 2 // 128 * 128)
+        Wf = pack.frag32_or_none(W)   # the model's packed layer carries the fragment-major copy: the W-direct kernel where it applies
+        hip.gemm(A, W, dtype="bf16", epilogue=hip.EPI_ROPE, rope=(cos, sin), rope_seq=M, rope_cols=(N // 3) * 2 // 128 * 128, **({"w_frag": Wf} if Wf is not None else {}))
     else:
         hip.gemm(A, W, dtype="bf16")
 torch.cuda.synchronize()

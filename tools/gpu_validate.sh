@@ -1,12 +1,12 @@
-# Round-end validation on the GPU box: full GPU test suite, smoke(), the default bench line and a rocprofv3 kernel trace of a short bench run.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- "bash tools/gpu_validate.sh [outdir]"   (outputs under gpurun_out/<outdir>, default "validate")
+# Round-end validation on the GPU box: full GPU test suite, smoke(), the default bench line (two clips in flight + the single-stream bracket), the other
+# configs, and rocprofv3 kernel traces of a short bench run with one stream (clean per-kernel durations, gaps) and with the default two.
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- "bash tools/gpu_validate.sh [outdir]"   (outputs under gpurun_out/<outdir>, default "validate")
 O=gpurun_out/${1:-validate}; mkdir -p $O
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > $O/gpu_tests.log; tail -2 $O/gpu_tests.log
+(timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > $O/gpu_tests.log; tail -2 $O/gpu_tests.log
 (timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2) > $O/smoke.log; tail -1 $O/smoke.log
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; python -c "
-import json; d=json.load(open('$O/bench.json')); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d.get('fp16',{}).get('ms_per_step'), d['cpu_baseline']['value'])"
-export TMPDIR=/tmp; cd /tmp; (timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --no-projection > $GRAFT_REPO_ROOT/$O/prof_bench.json 2> $GRAFT_REPO_ROOT/$O/prof.err); cd $GRAFT_REPO_ROOT
-find $O/prof -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_gaps.py {} --steps 3 > $O/gaps.md; head -8 $O/gaps.md
-find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c "python tools/prof_summary.py {} --div 24 --top 40 > $O/kernel_stats.md; cp {} $O/kernel_stats.csv"
-rm -rf $O/prof
-head -c 400 $O/prof_bench.json
+import json; d=json.load(open('$O/bench.json')); print(d['ms_per_step'], d['value'], d.get('single_stream'), d['roofline']['frac'], d.get('fp16',{}).get('ms_per_step'), d['cpu_baseline']['value'])"
+for c in c3 c4 c5; do timeout 600 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-projection > $O/bench_$c.json 2> $O/bench_$c.err; python -c "
+import json; d=json.load(open('$O/bench_$c.json')); print('$c', d['ms_per_step'], d.get('single_stream'), d.get('parity', {}).get('logits_max_abs_err'))"; done
+bash tools/gpu_profile.sh ${1:-validate}/prof_1stream 1 > /dev/null 2>&1; head -5 $O/prof_1stream/gaps.md
+bash tools/gpu_profile.sh ${1:-validate}/prof_2streams 2 > /dev/null 2>&1; head -3 $O/prof_2streams/kernel_stats.md

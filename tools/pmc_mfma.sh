@@ -29,11 +29,11 @@ for d in sorted(glob.glob(os.path.join(out, "*x*_*"))):
         continue
     per = {}
     for r in csv.DictReader(open(fs[0])):
-        if re.search(r"gemm_(p8|w4|sk)?_?kernel", r["Kernel_Name"]):
+        if re.search(r"gemm_(p8|w4|sk|t1|wd)?_?kernel", r["Kernel_Name"]):
             per.setdefault(r["Dispatch_Id"], {"k": r["Kernel_Name"]})[r["Counter_Name"]] = float(r["Counter_Value"])
     disp = [per[k] for k in sorted(per, key=int)][1:]          # drop the first (cold) launch
     kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
-    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if re.search(r"gemm_(p8|w4|sk)?_?kernel", r["Kernel_Name"])][1:] if kt else []
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if re.search(r"gemm_(p8|w4|sk|t1|wd)?_?kernel", r["Kernel_Name"])][1:] if kt else []
     dur_us = sum(durs) / len(durs) / 1e3 if durs else 0.0
     if not disp:
         continue

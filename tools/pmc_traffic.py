@@ -16,7 +16,7 @@ def per_launch(outdir, counter):
         raise SystemExit(f"no counter_collection.csv under {outdir}/{counter}")
     vals, name = [], None
     for r in csv.DictReader(open(files[0])):
-        if r["Counter_Name"] == counter and re.search(r"gemm_(p8|w4|sk)?_?kernel", r["Kernel_Name"]):
+        if r["Counter_Name"] == counter and re.search(r"gemm_(p8|w4|sk|t1|wd)?_?kernel", r["Kernel_Name"]):
             vals.append(float(r["Counter_Value"]))
             name = r["Kernel_Name"]
     if not vals:
@@ -27,11 +27,11 @@ def per_launch(outdir, counter):
 
 def symbol(kernel_name):
     """the demangled device symbol -> the short name bench.py gets from stllm_last_kernel()"""
-    m = re.search(r"(gemm_(?:p8_|w4_|sk_)?kernel)<([^>]*)>", kernel_name)
+    m = re.search(r"(gemm_(?:p8_|w4_|sk_|t1_|wd_)?kernel)<([^>]*)>", kernel_name)
     fam, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     epi = ["STORE", "RESID", "SWIGLU", "ROPE", "PATCH"]
     b = lambda x: "1" if x == "true" else "0" if x == "false" else x
-    if fam == "gemm_p8_kernel":      # <T, MIW, EPI, ACT, OF32>
+    if fam in ("gemm_p8_kernel", "gemm_t1_kernel", "gemm_wd_kernel"):      # <T, MIW | NRW | WM, EPI, ACT, OF32>
         return f"{fam}<{args[0]},{args[1]},{epi[int(args[2])]},{args[3]},{b(args[4])}>"
     if fam == "gemm_w4_kernel":      # <T, WM, WN, EPI, ACT, OF32>
         return f"{fam}<{args[0]},{args[1]},{args[2]},{epi[int(args[3])]},{args[4]},{b(args[5])}>"
