@@ -132,11 +132,6 @@ typedef struct {
    * W fragments go straight into registers, only A is staged through the LDS.  W itself must still be valid (other shapes / kernels read it).
    * Replaces nothing in the reference: a layout of the nn.Linear weight of modeling_llama_mem.py:130-144, 172-248. */
   const void* w_frag;
-  /* optional, ABI version >= 7 (16-bit dtypes): an LDS-IMAGE copy of W for the one-wave kernel's tile width w_lds_bn (128 / 192 / 256 columns) —
-   * [N / w_lds_bn][K / 64][w_lds_bn rows][8 chunks of 16 B], chunk slot c of row r holding logical chunk c ^ ((r >> 1) & 7) of that row's 64-deep K unit
-   * (st-llm_amd/pack.py: lds_image), + 1 KiB of slack behind it.  When the dispatcher picks a gemm_w4 tile of that width (N % w_lds_bn == 0) its W pieces are
-   * contiguous 1-KiB requests.  W itself must still be valid.  Replaces nothing in the reference: a layout of the nn.Linear weights of eva_vit.py:54-61, 118-148. */
-  const void* w_lds; int w_lds_bn;
 } stllm_gemm_args;
 enum { STLLM_SPLIT_A_PRESPLIT = 1, STLLM_SPLIT_OUT = 2 };
 int64_t stllm_gemm_split_ws_bytes(int M, int N, int K, int epilogue, int split_flags);

@@ -47,7 +47,6 @@ StllmOptions& stllm_options() {
     o.gemm_t1 = env_int("STLLM_GEMM_T1", -1);
     o.gemm_wd = env_int("STLLM_GEMM_WD", -1);
     o.attn_q_lds = env_int("STLLM_ATTN_Q_LDS", 1);
-    o.gemm_w_lds = env_int("STLLM_GEMM_W_LDS", 1);
     o.gemm_w4_odd = env_int("STLLM_GEMM_W4_ODD", 1);
     o.gemm_w4_wide = env_int("STLLM_GEMM_W4_WIDE", 1);
     o.attn_f32_mfma = env_int("STLLM_ATTN_F32_MFMA", 1);
@@ -72,7 +71,6 @@ extern "C" int stllm_set_option(const char* key, int value) {
   if (!strcmp(key, "gemm_t1")) { o.gemm_t1 = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_wd")) { o.gemm_wd = value; return STLLM_OK; }
   if (!strcmp(key, "attn_q_lds")) { o.attn_q_lds = value; return STLLM_OK; }
-  if (!strcmp(key, "gemm_w_lds")) { o.gemm_w_lds = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_odd")) { o.gemm_w4_odd = value; return STLLM_OK; }
   if (!strcmp(key, "gemm_w4_wide")) { o.gemm_w4_wide = value; return STLLM_OK; }
   if (!strcmp(key, "attn_f32_mfma")) { o.attn_f32_mfma = value; return STLLM_OK; }

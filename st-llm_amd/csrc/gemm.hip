@@ -1063,10 +1063,8 @@ int dispatch_epi(const stllm_gemm_args* a, const GemmParams& p, hipStream_t stre
         if (t24 >= 192 && t24 <= 256) { shape = 24; w4_go = true; }
       }
       if (w4_go) {
-        GemmParams q = p;   // the LDS-image copy of W only for the tile width it was packed for
-        q.Wl = (a->w_lds != nullptr && a->w_lds_bn == 64 * (shape % 10) && p.N % a->w_lds_bn == 0 && p.K % 64 == 0 && o_.gemm_w_lds != 0) ? reinterpret_cast<const char*>(a->w_lds) : nullptr;
-        const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, q, stream)
-                                                      : stllm_gemm_w4_launch_f16(a->epilogue, shape, q, stream);
+        const int rc = std::is_same<T, bf16_t>::value ? stllm_gemm_w4_launch_bf16(a->epilogue, shape, p, stream)
+                                                      : stllm_gemm_w4_launch_f16(a->epilogue, shape, p, stream);
         if (rc != STLLM_ERR_UNSUPPORTED) return rc;
       }
     }

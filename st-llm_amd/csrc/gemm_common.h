@@ -24,7 +24,6 @@ struct GemmParams {
   int p8_q, p8_r, p8_s, p8_cap;    // phased kernel schedule: DP rounds, remainder tiles, K-slices per remainder tile, groups per XCD
   const float* nx; int64_t nx_ld; const float* ngamma; float neps;   // GEMV only: A := RMSNorm(nx) * ngamma (fp32 rows, stride nx_ld elements)
   const char* Wf;                  // gemm_wd only: fragment-major copy of W (pack.frag32: [N / 32][K / 16][64 lanes x 16 B]) or nullptr
-  const char* Wl;                  // gemm_w4 only: LDS-image copy of W for the chosen tile width (pack.lds_image; set by the dispatcher when stllm_gemm_args.w_lds_bn matches) or nullptr
   int w4_thin;                     // gemm_w4 only: the last M % tile_rows (<= 32) rows are computed outside the tile grid (0 = none)
 };
 

@@ -15,7 +15,6 @@ struct StllmOptions {
   int attn_f32_mfma;       // STLLM_ATTN_F32_MFMA: 1 (default) fp32 attention on the exact-fp32 matrix-core kernel from 8 query rows on | 0 the vector kernel (round 1-3) everywhere
   int gemm_t1;             // STLLM_GEMM_T1: -1 auto | 0 off | 2 / 4 / 6 force the tall-tile one-round kernel (gemm_t1.inc) with that many column fragments per wave wherever it is eligible
   int gemm_wd;             // STLLM_GEMM_WD: -1 auto | 0 off | 4 / 6 force the W-direct kernel (gemm_wd.inc) with that many 32-row fragments per tile wherever it is eligible
-  int gemm_w_lds;          // STLLM_GEMM_W_LDS: 1 (default) the one-wave kernel reads W from the caller's LDS-image copy when one is given for its tile width | 0 never (A/B)
   int attn_q_lds;          // STLLM_ATTN_Q_LDS: 1 (default) the LDS-DMA attention kernels stage their query tiles through the LDS (row-contiguous requests, one copy per tile) | 0 per-lane fragment loads from global memory (rounds 2-5)
   int norm_fast;           // STLLM_NORM_FAST: 1 (default) one row per wave | 2 two rows per wave for >= 2048 short rows (bit-identical; measured equal: 22.36 / 22.47 / 22.41 / 22.40 ms per step)
 };

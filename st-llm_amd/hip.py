@@ -47,7 +47,7 @@ class GemmArgs(ctypes.Structure):
                 ("o_rows_per_batch", c_int), ("o_batch_stride", c_int64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64),
                 ("a_norm_x", c_void_p), ("a_norm_ldx", c_int64), ("a_norm_gamma", c_void_p), ("a_norm_eps", ctypes.c_float),
-                ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("split_flags", c_int), ("w_frag", c_void_p), ("w_lds", c_void_p), ("w_lds_bn", c_int)]
+                ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("split_flags", c_int), ("w_frag", c_void_p)]
 
 
 class VitBlockWeights(ctypes.Structure):
@@ -441,7 +441,7 @@ def set_profiler(p):
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False, act=ACT_NONE, resid=None,
          rope=None, rope_seq=0, rope_cols=0, frames=None, pos_embed=None, n_frames=0, M=None,
-         a_rows=None, o_rows=None, a_norm=None, a_presplit=False, out_split=False, w_frag=None, w_lds=None):
+         a_rows=None, o_rows=None, a_norm=None, a_presplit=False, out_split=False, w_frag=None):
     """out = epilogue(a @ w.T).  a [M,K] (compute dtype), w [N,K] (compute dtype, maybe padded).
     dtype fp32 with a bf16 weight of 3 K columns (pack.split3_weight: the runtime's "bf16x3" mode) selects STLLM_BF16X3: a and every output
     stay fp32, the product runs as three bf16 matrix-core passes (stllm_hip.h).  In that mode a_presplit = a is ALREADY the split image bf16 [M, 3 K]
@@ -493,12 +493,6 @@ def gemm(a, w, *, dtype, epilogue=EPI_STORE, bias=None, out=None, out_f32=False,
         if w_frag.numel() != w.shape[0] * K:
             raise RuntimeError("gemm: w_frag must hold N x K elements (pack.frag32 of the un-padded weight)")
         args.w_frag = _p(w_frag)
-    if w_lds is not None:    # (pack.lds_image(w, bn), bn): the LDS-image copy for the one-wave kernel's tiles of bn columns
-        img, bn = w_lds
-        _req(img, td, "w_lds")
-        if img.numel() < w.shape[0] * K + 512 or w.shape[0] % bn or K % 64:
-            raise RuntimeError("gemm: w_lds must be pack.lds_image of the un-padded weight (N x K elements + 512 of slack, N % bn == 0, K % 64 == 0)")
-        args.w_lds, args.w_lds_bn = _p(img), int(bn)
     if bias is not None:
         _req(bias, torch.float32, "bias")
     args.bias = _p(bias)

@@ -94,22 +94,6 @@ def frag32(w):
     return w.reshape(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
-def lds_image(w, bn):
-    """LDS-image copy of a packed 16-bit weight [N, K] (N % bn == 0, K % 64 == 0) for the one-wave GEMM's tiles of bn columns (csrc/gemm_w4.inc,
-    stllm_gemm_args.w_lds): [N / bn][K / 64][bn rows][8 chunks of 8 elements], chunk slot c of row r = logical chunk c ^ ((r >> 1) & 7) of that row's
-    64-deep K unit (the kernel's source-side bank swizzle, applied here once) — one K unit of a tile's W operand is bn x 128 contiguous bytes, a DMA piece
-    one contiguous KiB.  512 elements of slack behind the image (the kernel's drained pipeline reads 16 bytes past the last unit)."""
-    n, k = w.shape
-    assert n % bn == 0 and k % 64 == 0 and w.element_size() == 2
-    x = w.reshape(n // bn, bn, k // 64, 8, 8).permute(0, 2, 1, 3, 4)          # [tn, unit, r, logical chunk, e]
-    r = torch.arange(bn, device=w.device)
-    src = (torch.arange(8, device=w.device).view(1, 8) ^ ((r >> 1) & 7).view(bn, 1))   # slot c of row r <- logical chunk c ^ sw(r)
-    x = torch.gather(x, 3, src.view(1, 1, bn, 8, 1).expand(n // bn, k // 64, bn, 8, 8))
-    out = torch.zeros(n * k + 512, dtype=w.dtype, device=w.device)
-    out[: n * k] = x.reshape(-1)
-    return out
-
-
 def frag32_or_none(w):
     """frag32(w) where the W-direct kernel can use it: a 16-bit weight on the GPU with N % 256 == 0 and K % 256 == 0 (un-padded, contiguous rows);
     STLLM_WD_FRAG=0 in the environment: never (the prefill runs on the other kernels, no second copy of the weights)."""
