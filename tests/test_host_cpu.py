@@ -31,7 +31,7 @@ def test_abi_exports_match_header():
     for name in sorted(declared):
         assert hasattr(L, name), f"libstllm_hip.so does not export {name}"
     assert set(hip.EXPORTS) == declared, (set(hip.EXPORTS) ^ declared)
-    assert L.stllm_abi_version() == 6
+    assert L.stllm_abi_version() == 7   # round 6: stllm_gemm_args.w_frag, stllm_llama_layer_weights.wqkv_frag / wgu_frag
 
 
 def test_phased_gemm_schedule_invariants():
