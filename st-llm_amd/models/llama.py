@@ -69,16 +69,18 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
 
-    def pack(self, dt, n_heads):
+    def pack(self, dt, n_heads, frag=True):
         a, m = self.self_attn, self.mlp
         pk = dict(ln1=self.input_layernorm.weight, ln2=self.post_attention_layernorm.weight,
                   wqkv=pack.llama_qkv(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, dt, n_heads),
                   wo=pack.linear(a.o_proj.weight, dt),
                   wgu=pack.llama_gate_up(m.gate_proj.weight, m.up_proj.weight, dt),
                   wdown=pack.linear(m.down_proj.weight, dt))
-        # fragment-major copies for the W-direct prefill GEMM (csrc/gemm_wd.inc, round 6): + 2 x (qkv + gate/up) bytes per layer (8.9 GB at 7B in 16 bits)
-        for k in ("wqkv", "wgu"):
-            pk[k + "_frag"] = pack.frag32_or_none(pk[k]) if dt != torch.float32 else None   # (fp32 / bf16x3: other kernels)
+        # fragment-major copy of wqkv for the W-direct prefill GEMM (csrc/gemm_wd.inc, round 6): + 100 MB per layer (3.2 GB at 7B in 16 bits).  The gate/up
+        # weight gets none: its 86 column blocks never make the one-round plans the dispatcher takes (measured equal or slower, profiles/r06_bench_ab_wd.log);
+        # the C entry point and hip.gemm accept one all the same (stllm_llama_layer_weights.wgu_frag, w_frag=)
+        pk["wqkv_frag"] = pack.frag32_or_none(pk["wqkv"]) if (frag and dt != torch.float32) else None   # (fp32 / bf16x3: other kernels)
+        pk["wgu_frag"] = None
         return pk
 
 
@@ -113,6 +115,8 @@ class LlamaModel(nn.Module):
         self._rope = {}
         self._carr = {}   # C-side table of the packed layers (+ the cache it points into): rebuilt when either changes
         self._plist = ParamList(lambda: self.layers.parameters())
+        self.wd_frag = True   # keep fragment-major copies of wqkv / wgu next to the packed weights (W-direct prefill GEMM); the training step switches this off:
+                              # its weights change every step and its taped forward does not use the copies
 
     def pack(self, dtype=None):
         dt = hip.torch_dtype(dtype) if dtype is not None else runtime.compute_dtype()
@@ -121,7 +125,7 @@ class LlamaModel(nn.Module):
         if hit is None or hit[0] != fp:
             self._packed = {}  # one packed copy at a time (13.5 GB at 7B) ...
             self._carr = {}    # ... including the C-side table, which holds a reference to the list it was built from
-            hit = (fp, [l.pack(dt, self.config.num_attention_heads) for l in self.layers])
+            hit = (fp, [l.pack(dt, self.config.num_attention_heads, frag=self.wd_frag) for l in self.layers])
             self._packed[dt] = hit
         return hit[1]
 

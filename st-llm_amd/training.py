@@ -94,6 +94,7 @@ def llama_forward_taped(lm, inputs_embeds, attention_mask=None):
     """LlamaModel.prefill (models/llama.py) with every activation kept.  Returns (h32 [B,S,D], h16 [B*S,D], tape)."""
     cfg = lm.config
     dt = runtime.compute_dtype()
+    lm.wd_frag = False   # (the weights are re-packed after every optimizer step: no second, fragment-major copy of wqkv / wgu for kernels this path does not call)
     packs = lm.pack(dt)
     B, S, D = inputs_embeds.shape
     H = cfg.num_attention_heads
