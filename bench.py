@@ -734,7 +734,10 @@ def _run(args, world, rank, device, dry):
         mask = draw_mask(Lvis, B)
         samples["mask"] = mask
 
-    n_streams = max(1, args.streams) if (world == 1 and not dry) else 1
+    # clips in flight: also on every rank of an N > 1 run as long as the step has no exchange inside (c2 weak scaling: one whole clip per rank, teams of one) —
+    # the per-N values the driver divides must be measured the same way at every N; a step with a token exchange / sequence-parallel prefill keeps one stream
+    exchange_in_step = bool(world > 1 and sm.vit_model == "eva_clip_g" and sm._team_plan(B, T).exchange_needed())
+    n_streams = max(1, args.streams) if (not dry and not exchange_in_step) else 1
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else []
     step_no = [0]
 
