@@ -352,6 +352,8 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
         ref_blocks = {}
         for c in plan.clips_of(0):      # the clips rank 0 prefills (a share of): every member's sub-block, computed as that member computes it
             ref_blocks[c] = torch.cat([_encode_as_rank(sm, samples, plan, m, T, dt)[c] for m, (f0, f1) in zip(plan.team[c], plan.frames[c]) if f1 > f0], dim=0)
+            if sm.fp_wire_dtype() is not None and len(plan.team[c]) > 1:   # 16-bit wire: every member (the sender too) holds the sub-blocks rounded through it
+                ref_blocks[c] = ref_blocks[c].to(sm.fp_wire_dtype()).float()
     sync()
     # ---- N GPUs -----------------------------------------------------------------------------------------
     sm.set_frame_parallel(rank, world)
@@ -389,16 +391,18 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     msN, msL = float(t[0].item()) / stepsN * 1e3, float(t[1].item()) / stepsL * 1e3
     # ---- the token exchange on its own (same shapes, same stream) --------------------------------------
-    local = {c: torch.zeros((f1 - f0, 32, 4096), dtype=torch.float32, device=device) for c, f0, f1 in plan.encodes(rank)}
+    local = {c: torch.zeros((f1 - f0, sm.tokens_per_frame, 4096), dtype=torch.float32, device=device) for c, f0, f1 in plan.encodes(rank)}
     x_us = 0.0
+    wire = sm.fp_wire_dtype()
+    wire_bytes = 2 if wire is not None else 4
     if plan.exchange_needed():
         for _ in range(3):
-            parallel.exchange_clip_tokens(local, plan, rank, device=device)
+            parallel.exchange_clip_tokens(local, plan, rank, device=device, token_shape=(sm.tokens_per_frame, 4096), wire_dtype=wire)
         sync()
         t1 = time.perf_counter()
         reps = 2 if dry else 20
         for _ in range(reps):
-            parallel.exchange_clip_tokens(local, plan, rank, device=device)
+            parallel.exchange_clip_tokens(local, plan, rank, device=device, token_shape=(sm.tokens_per_frame, 4096), wire_dtype=wire)
         sync()
         x_us = (time.perf_counter() - t1) / reps * 1e6
     R = mconf["residual_size"]
@@ -410,7 +414,8 @@ def frame_parallel_leg(args, world, rank, device, dry, sync):
            "video_tokens_per_s": round(B * R * 32 / (msN * 1e-3), 1), "frames_per_s": round(n_frames / (msN * 1e-3), 1),
            "plan": plan.describe(), "sequence_parallel_prefill": bool(any(plan.sp)),
            "token_exchange_us": round(x_us, 1), "token_exchange_in_step": bool(plan.exchange_needed()),
-           "token_exchange_bytes_sent_per_rank": [sum((f1 - f0) * 32 * 4096 * 4 * (len(plan.receivers(c)) - (1 if r in plan.receivers(c) else 0)) for c, f0, f1 in plan.encodes(r))
+           "token_exchange_wire_dtype": str(wire).replace("torch.", "") if wire is not None else "float32",
+           "token_exchange_bytes_sent_per_rank": [sum((f1 - f0) * sm.tokens_per_frame * 4096 * wire_bytes * (len(plan.receivers(c)) - (1 if r in plan.receivers(c) else 0)) for c, f0, f1 in plan.encodes(r))
                                                   for r in range(world)],
            "frames_per_rank": [sum(f1 - f0 for _, f0, f1 in plan.encodes(r)) for r in range(world)],
            "clips_per_rank": [len(plan.clips_of(r)) for r in range(world)],
@@ -589,7 +594,7 @@ def frame_parallel_projection(args, device):
                 meas[k] = (enc_ms, step_ms)
             tok_ms = sp_lag = 0.0
             if plan.exchange_needed():
-                tok_ms = max(model_p2p_ms((f1 - f0) * 32 * 4096 * 4) for c in range(B) for f0, f1 in plan.frames[c] if f1 > f0)   # the pairs run concurrently, each on its own link
+                tok_ms = max(model_p2p_ms((f1 - f0) * sm.tokens_per_frame * 4096 * (2 if sm.fp_wire_dtype() is not None else 4)) for c in range(B) for f0, f1 in plan.frames[c] if f1 > f0)   # the pairs run concurrently, each on its own link
             if any(plan.sp):
                 kmax = max(len(plan.team[c]) for c in range(B) if plan.sp[c])
                 sp_lag = (kmax - 1) * model_p2p_ms(S // kmax * 2 * 4096 * 2)     # member j trails member j - 1 by one K | V hand-over; the last layer's is exposed

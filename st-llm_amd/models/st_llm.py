@@ -129,6 +129,12 @@ class STLLMModel(Blip2Base):
         self.fp_mailbox = mailbox
         self._sp_state = None
 
+    def fp_wire_dtype(self):
+        """dtype of the token sub-blocks on the wire (parallel.exchange_clip_tokens): the compute dtype in the 16-bit modes (half the bytes per xGMI link; the
+        first RMSNorm rounds these tokens to it anyway), fp32 (None) in the verify modes; `fp_wire16 = False` keeps fp32 everywhere."""
+        dt = runtime.compute_dtype()
+        return dt if (getattr(self, "fp_wire16", True) and dt in (torch.bfloat16, torch.float16) and not runtime.gemm_split()) else None
+
     def _team_plan(self, n_clips, T):
         """the TeamPlan of a batch of n_clips x T frames on this model's ranks.  The prefill is shared inside a team (sequence-parallel) unless the
         forward needs two prefills and a loss over rows of both (MVM: use_mask, st_llm.py:71-91) — then the owner prefills alone."""
@@ -206,7 +212,8 @@ class STLLMModel(Blip2Base):
                 for c, f0, f1 in enc:
                     local[c] = toks[o: o + (f1 - f0)]
                     o += f1 - f0
-            blocks = parallel.exchange_clip_tokens(local, plan, rank, group, self.fp_mailbox, token_shape=(self.tokens_per_frame, 4096), device=image.device)
+            blocks = parallel.exchange_clip_tokens(local, plan, rank, group, self.fp_mailbox, token_shape=(self.tokens_per_frame, 4096), device=image.device,
+                                                   wire_dtype=self.fp_wire_dtype())
             need = plan.clips_of(rank)
             self._fp_local_clips = True
             if getattr(self, "_fp_keep_tokens", False):   # bench.py / tests: the blocks as they arrived, per clip

@@ -136,7 +136,7 @@ def test_team_plan_tables():
     assert rr[0][0] == 0 and rr[-1][1] == 2320 and all(a[1] == b[0] for a, b in zip(rr, rr[1:])) and all(e % 32 == 0 for _, e in rr[:-1])
 
 
-def _team_worker(rank, world, port, clips, T, sp, q):
+def _team_worker(rank, world, port, clips, T, sp, q, wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from stllm_amd import parallel
@@ -144,10 +144,36 @@ def _team_worker(rank, world, port, clips, T, sp, q):
     frames = torch.randn(clips * T, 3, 16, 16)
     plan = parallel.TeamPlan(clips, T, world, sp=sp, balance="throughput", prefill_cost_frames=1.0)
     local = {c: _encode(frames[c * T + f0: c * T + f1]) for c, f0, f1 in plan.encodes(rank)}
-    blocks = parallel.exchange_clip_tokens(local, plan, rank, token_shape=(32, 8))
+    blocks = parallel.exchange_clip_tokens(local, plan, rank, token_shape=(32, 8), wire_dtype=wire)
     q.put((rank, {c: b.numpy().copy() for c, b in blocks.items()}, plan.clips_of(rank)))   # arrays: pickled by value (a tensor travels as a shared-memory handle that dies with the worker)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_clip_team_exchange_on_a_16_bit_wire():
+    """VERDICT r05 #8b: wire_dtype = bfloat16 — the sub-blocks travel in 16 bits and the sender rounds its own copy through the same dtype: every member of
+    a team assembles the SAME bits (the fp32 block rounded through bf16), half the bytes per link."""
+    world, clips, T = 4, 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_team_worker, args=(r, world, port, clips, T, True, q, torch.bfloat16)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _encode(torch.randn(clips * T, 3, 16, 16)).view(clips, T, 32, 8)
+    ref16 = ref.to(torch.bfloat16).float()
+    assert not torch.equal(ref, ref16)
+    n = 0
+    for rank, blocks, own in res:
+        for c, b in blocks.items():
+            assert torch.equal(torch.from_numpy(b), ref16[c]), f"rank {rank} clip {c}: not the fp32 block rounded through the wire dtype"
+            n += 1
+    assert n == 4      # two teams of two, both members hold their clip's block
 
 
 @pytest.mark.parametrize("world,clips,T,sp", [(2, 1, 5, True), (4, 2, 6, True), (4, 2, 6, False), (4, 1, 3, True), (2, 3, 2, True)])
