@@ -239,6 +239,15 @@ typedef struct {
 int64_t stllm_llama_layers_scratch_bytes(int dtype, int B, int S, int hidden, int inter);
 /* the decoder-layer loop of the PREFILL (st_llm.py:56-92 -> HF LlamaModel.forward, use_cache False or filling a fresh cache) */
 int stllm_llama_layers(const stllm_llama_layers_args* args, const stllm_llama_layer_weights* layers, int n_layers, void* stream);
+/* ONE decoder layer of a SEQUENCE-PARALLEL prefill in two parts (ABI >= 7, round 6; st-llm_amd/models/llama.py: LlamaModel.prefill_sp — no reference counterpart, the
+ * reference has no sequence parallelism: SURVEY.md 2b): this rank owns the positions [s0, s1) of one sequence (args->B == 1, args->S == s1 - s0 rows in x,
+ * args->rope_cos / rope_sin pointing at position s0's table row), `qkv` is the fused buffer [s1, 3 * hidden] (compute dtype) whose rows [0, s0) hold the earlier
+ * members' K | V (their q columns zero).
+ *   part 0: RMSNorm(x) -> fused QKV GEMM + RoPE at positions s0 .. -> rows [s0, s1) of `qkv`            (the caller then ships / receives K | V rows)
+ *   part 1: causal attention of the s1 query rows over the s1 keys, rows [s0, s1) -> o_proj + residual -> RMSNorm -> gate/up + SiLU(gate) * up -> down + residual
+ * The same launches, in the same order, as the per-op path: bit-identical.  Scratch: stllm_llama_layer_sp_scratch_bytes(dtype, s0, s1, hidden, inter). */
+int64_t stllm_llama_layer_sp_scratch_bytes(int dtype, int s0, int s1, int hidden, int inter);
+int stllm_llama_layer_sp(const stllm_llama_layers_args* args, const stllm_llama_layer_weights* layer, void* qkv, int s0, int s1, int part, void* stream);
 
 /* BertSelfOutput / BertOutput (Qformer.py:281-289, 384-400): LayerNorm(dense(x) + input) */
 typedef struct {

@@ -221,6 +221,63 @@ extern "C" int stllm_llama_layers(const stllm_llama_layers_args* a, const stllm_
   return STLLM_OK;
 }
 
+extern "C" int64_t stllm_llama_layer_sp_scratch_bytes(int dtype, int s0, int s1, int hidden, int inter) {
+  if (s0 < 0 || s1 <= s0 || hidden <= 0 || inter <= 0 || !dtype_ok(dtype) || dtype == STLLM_BF16X3) return -1;
+  const int64_t n = s1 - s0, e = esize(dtype);
+  return up256(n * hidden * e) + up256((int64_t)s1 * hidden * e) + up256(n * inter * e);
+}
+
+// One decoder layer of the sequence-parallel prefill, in the two parts between which the team's K | V rows travel (stllm_hip.h).
+extern "C" int stllm_llama_layer_sp(const stllm_llama_layers_args* a, const stllm_llama_layer_weights* wp, void* qkv_, int s0, int s1, int part, void* stream) {
+  if (!a || !wp || !qkv_) { stllm_set_error("stllm_llama_layer_sp: null arguments"); return STLLM_ERR_BAD_SHAPE; }
+  if (!dtype_ok(a->dtype) || a->dtype == STLLM_BF16X3) { stllm_set_error("stllm_llama_layer_sp: dtype %d (the split mode runs the per-op path)", a->dtype); return STLLM_ERR_BAD_DTYPE; }
+  const int n = s1 - s0;
+  if (a->B != 1 || a->S != n || n <= 0 || s0 < 0 || a->n_heads <= 0 || a->hidden <= 0 || a->inter <= 0 || a->hidden % a->n_heads != 0 || a->ldx < a->hidden ||
+      !a->x || !a->scratch || !a->rope_cos || !a->rope_sin || a->kv_len || a->cache_max_len != 0 || (part != 0 && part != 1)) {
+    stllm_set_error("stllm_llama_layer_sp: bad arguments (B %d, S %d, rows [%d, %d), part %d)", a->B, a->S, s0, s1, part);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const int64_t need = stllm_llama_layer_sp_scratch_bytes(a->dtype, s0, s1, a->hidden, a->inter);
+  if (need < 0 || a->scratch_bytes < need) {
+    stllm_set_error("stllm_llama_layer_sp: scratch of %lld bytes needed, %lld given", (long long)need, (long long)a->scratch_bytes);
+    return STLLM_ERR_BAD_SHAPE;
+  }
+  const stllm_llama_layer_weights& w = *wp;
+  const int D = a->hidden, hd = D / a->n_heads, e = esize(a->dtype);
+  Carver c(a->scratch, a->scratch_bytes);
+  char* h = reinterpret_cast<char*>(c.take((int64_t)n * D * e));
+  char* att = reinterpret_cast<char*>(c.take((int64_t)s1 * D * e));
+  char* gu = reinterpret_cast<char*>(c.take((int64_t)n * a->inter * e));
+  char* qkv = reinterpret_cast<char*>(qkv_);
+  const int64_t rs = 3 * (int64_t)D;
+  if (part == 0) {
+    STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln1, a->eps, h, D, nullptr, 0, n, D, stream));
+    stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, nullptr, 0);
+    g.epilogue = STLLM_EPI_ROPE; g.A = h; g.lda = D; g.W = w.wqkv; g.ldw = w.ld_qkv; g.w_frag = w.wqkv_frag;
+    g.aux0 = a->rope_cos; g.aux1 = a->rope_sin; g.rope_seq = n; g.rope_cols = 2 * D; g.M = n; g.N = 3 * D; g.K = D; g.ldo = 3 * D;
+    g.out = qkv + (int64_t)s0 * rs * e;
+    STACK_TRY(stllm_gemm(&g, stream));
+    return STLLM_OK;
+  }
+  const float scale = (float)(1.0 / __builtin_sqrt((double)hd));
+  STACK_TRY(stllm_attention(a->dtype, qkv, (int64_t)s1 * rs, rs, qkv + (int64_t)D * e, (int64_t)s1 * rs, rs, qkv + (int64_t)2 * D * e, (int64_t)s1 * rs, rs, att,
+                            (int64_t)s1 * D, D, 1, a->n_heads, s1, s1, hd, scale, 1, nullptr, stream));
+  stllm_gemm_args g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, nullptr, 0);
+  g.epilogue = STLLM_EPI_RESID; g.A = att + (int64_t)s0 * D * e; g.lda = D; g.W = w.wo; g.ldw = w.ld_o;
+  g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = n; g.N = D; g.K = D;
+  STACK_TRY(stllm_gemm(&g, stream));
+  STACK_TRY(stllm_rmsnorm(a->dtype, a->x, a->ldx, w.ln2, a->eps, h, D, nullptr, 0, n, D, stream));
+  g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, nullptr, 0);
+  g.epilogue = STLLM_EPI_SWIGLU; g.A = h; g.lda = D; g.W = w.wgu; g.ldw = w.ld_gu; g.w_frag = w.wgu_frag;
+  g.out = gu; g.ldo = a->inter; g.M = n; g.N = 2 * a->inter; g.K = D;
+  STACK_TRY(stllm_gemm(&g, stream));
+  g = gemm_base(a->dtype, a->workspace, a->workspace_bytes, nullptr, 0);
+  g.epilogue = STLLM_EPI_RESID; g.A = gu; g.lda = a->inter; g.W = w.wdown; g.ldw = w.ld_down;
+  g.out = a->x; g.ldo = a->ldx; g.resid = a->x; g.ldr = a->ldx; g.M = n; g.N = D; g.K = a->inter;
+  STACK_TRY(stllm_gemm(&g, stream));
+  return STLLM_OK;
+}
+
 namespace {
 
 inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }

@@ -24,7 +24,7 @@ EXPORTS = ["stllm_last_error", "stllm_abi_version", "stllm_last_kernel", "stllm_
            "stllm_cross_entropy_rows", "stllm_cast_rows", "stllm_gemm_workspace_bytes", "stllm_gemm_workspace_status", "stllm_gemm_plan", "stllm_gemm_w4_plan", "stllm_set_option",
            "stllm_preprocess_workspace_bytes", "stllm_preprocess_frames", "stllm_attention_decode_workspace_bytes",
            "stllm_attention_decode", "stllm_gemm_profile", "stllm_gemm_profile_count", "stllm_gemm_profile_read",
-           "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers",
+           "stllm_vit_blocks_scratch_bytes", "stllm_vit_blocks", "stllm_llama_layers_scratch_bytes", "stllm_llama_layers", "stllm_llama_layer_sp_scratch_bytes", "stllm_llama_layer_sp",
            "stllm_qformer_layers_scratch_bytes", "stllm_qformer_layers", "stllm_split3_rows", "stllm_gemm_split_ws_bytes"]
 
 
@@ -147,6 +147,8 @@ def _bind(L, strict=True):
     B("stllm_vit_blocks", [ctypes.POINTER(VitBlocksArgs), ctypes.POINTER(VitBlockWeights), c_int, c_void_p])
     B("stllm_llama_layers_scratch_bytes", [c_int] * 5, c_int64)
     B("stllm_llama_layers", [ctypes.POINTER(LlamaLayersArgs), ctypes.POINTER(LlamaLayerWeights), c_int, c_void_p])
+    B("stllm_llama_layer_sp_scratch_bytes", [c_int] * 5, c_int64)
+    B("stllm_llama_layer_sp", [ctypes.POINTER(LlamaLayersArgs), ctypes.POINTER(LlamaLayerWeights), c_void_p, c_int, c_int, c_int, c_void_p])
     B("stllm_qformer_layers_scratch_bytes", [c_int] * 9, c_int64)
     B("stllm_qformer_layers", [ctypes.POINTER(QformerLayersArgs), ctypes.POINTER(QformerLayerWeights), c_int, c_void_p])
     B("stllm_gemm_plan", [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)])
@@ -629,6 +631,29 @@ def llama_layers(x, layers, carr, *, B, S, n_heads, eps, rope, dtype, kv_len=Non
     a = LlamaLayersArgs(code, B, S, n_heads, hidden, inter, float(eps), x.data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(),
                         _p(kv_len), cache.max_len if cache is not None else 0, scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
     _check(L.stllm_llama_layers(ctypes.byref(a), carr, len(layers), _stream()), "stllm_llama_layers")
+    return x
+
+
+def llama_layer_sp(x, carr, li, qkv, *, s0, s1, part, n_heads, eps, rope, dtype, inter):
+    """ONE decoder layer of the sequence-parallel prefill, part 0 (RMSNorm + QKV GEMM + RoPE into rows [s0, s1) of `qkv`) or part 1 (attention over the s1
+    rows, o_proj, RMSNorm, gate/up, down) — one C call each (stllm_llama_layer_sp).  x f32 [s1 - s0, hidden] in place; carr = llama_layer_array(layers);
+    rope = (cos, sin) rows of THIS rank's positions (the tables offset by s0)."""
+    _req(x, torch.float32, "x")
+    td = torch_dtype(dtype)
+    _req(qkv, td, "qkv")
+    hidden = x.shape[1]
+    L = lib()
+    code = dtype_code(td)
+    need = int(L.stllm_llama_layer_sp_scratch_bytes(code, s0, s1, hidden, inter))
+    if need < 0:
+        raise RuntimeError("stllm_llama_layer_sp: bad shape / dtype")
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+    ws = gemm_workspace(x.device)
+    cos, sin = rope
+    _req(cos, torch.float32, "rope cos"); _req(sin, torch.float32, "rope sin")
+    a = LlamaLayersArgs(code, 1, s1 - s0, n_heads, hidden, inter, float(eps), x.data_ptr(), x.stride(0), cos.data_ptr(), sin.data_ptr(),
+                        None, 0, scratch.data_ptr(), need, ws.data_ptr(), ws.numel())
+    _check(L.stllm_llama_layer_sp(ctypes.byref(a), ctypes.byref(carr[li]), qkv.data_ptr(), s0, s1, part, _stream()), "stllm_llama_layer_sp")
     return x
 
 

@@ -220,6 +220,27 @@ class LlamaModel(nn.Module):
             hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
         return x
 
+    def sp_layer_part(self, part, x, layers, li, qkv, s0, s1, cos_l, sin_l, dt, carr):
+        """one half of a decoder layer on this rank's rows [s0, s1) (prefill_sp): part 0 = RMSNorm + QKV GEMM + RoPE into qkv[s0:s1], part 1 = attention over
+        the s1 rows + o_proj + RMSNorm + gate/up + down.  carr: the C-side layer table (one stllm_llama_layer_sp call) or None (the per-op body)."""
+        cfg = self.config
+        D, H = cfg.hidden_size, cfg.num_attention_heads
+        hd = D // H
+        pk = layers[li]
+        if carr is not None:
+            return hip.llama_layer_sp(x, carr, li, qkv, s0=s0, s1=s1, part=part, n_heads=H, eps=cfg.rms_norm_eps, rope=(cos_l, sin_l), dtype=dt,
+                                      inter=pk["wgu"].shape[0] // 2)
+        if part == 0:
+            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
+            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos_l, sin_l), rope_seq=s1 - s0, rope_cols=2 * D, out=qkv[s0:s1], **_frag(pk, "wqkv"))
+            return x
+        a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=1, H=H, Sq=s1, Skv=s1, D=hd, scale=hd ** -0.5, causal=True)
+        hip.gemm(a[s0:s1], pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+        h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
+        g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU, **_frag(pk, "wgu"))
+        hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+        return x
+
     def prefill_sp(self, inputs_embeds, sp):
         """Sequence-parallel prefill of ONE sequence inside a clip team (stllm_amd.parallel, round 5): this rank runs the decoder layers on the
         positions [s0, s1) = parallel.sp_row_ranges(S, k)[j] only.  Causal attention makes the team's dependency one-directional: per layer the
@@ -254,11 +275,17 @@ class LlamaModel(nn.Module):
         if n_loc == 0:                     # more members than 32-row groups: this member has no rows (and nobody waits for any from it)
             return x.view(1, 0, D), x.to(dt), (s0, s1)
         pending = []                       # send handles + the packed buffers they read: kept until the end of the prefill
+        # round 6 (VERDICT r05 missing #4): the two halves of a layer — up to the QKV rows, and from the attention on — are ONE C call each
+        # (stllm_llama_layer_sp) instead of 2 + 5 per-op calls; the split verify mode and STACK_ENTRY = 0 keep the per-op body (bit-identical)
+        carr = None
+        if STACK_ENTRY and not runtime.gemm_split():
+            if self._carr.get("layers") is not layers:
+                self._carr = {"layers": layers, "carr": hip.llama_layer_array(layers)}
+            carr = self._carr["carr"]
         for li_, pk in enumerate(layers):
             recvs = [(torch.empty((rr[i][1] - rr[i][0], 2 * D), device=dev, dtype=dt), ranks[i], ("kv", li_)) for i in range(j) if rr[i][1] > rr[i][0]]
             works = parallel.p2p_exchange([], recvs, me, group, box) if recvs else []
-            h, _ = hip.rmsnorm(x, pk["ln1"], cfg.rms_norm_eps, dtype=dt)
-            hip.gemm(h, pk["wqkv"], dtype=dt, epilogue=hip.EPI_ROPE, rope=(cos_l, sin_l), rope_seq=n_loc, rope_cols=2 * D, out=qkv[s0:s1], **_frag(pk, "wqkv"))
+            self.sp_layer_part(0, x, layers, li_, qkv, s0, s1, cos_l, sin_l, dt, carr)
             later = [i for i in range(j + 1, k) if rr[i][1] > rr[i][0]]
             if later:
                 kv = qkv[s0:s1, D:].contiguous()
@@ -267,11 +294,7 @@ class LlamaModel(nn.Module):
                 w.wait()
             for (buf, _, _), i in zip(recvs, [i for i in range(j) if rr[i][1] > rr[i][0]]):
                 qkv[rr[i][0]:rr[i][1], D:].copy_(buf)
-            a = hip.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B=1, H=H, Sq=s1, Skv=s1, D=hd, scale=hd ** -0.5, causal=True)
-            hip.gemm(a[s0:s1], pk["wo"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
-            h, _ = hip.rmsnorm(x, pk["ln2"], cfg.rms_norm_eps, dtype=dt)
-            g = hip.gemm(h, pk["wgu"], dtype=dt, epilogue=hip.EPI_SWIGLU, **_frag(pk, "wgu"))
-            hip.gemm(g, pk["wdown"], dtype=dt, epilogue=hip.EPI_RESID, resid=x)
+            self.sp_layer_part(1, x, layers, li_, qkv, s0, s1, cos_l, sin_l, dt, carr)
         for _, ws in pending:
             for w in ws:
                 w.wait()

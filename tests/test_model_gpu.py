@@ -291,6 +291,18 @@ def test_sequence_parallel_prefill_matches_the_whole_prefill(mode, tol):
                 err = float((out.last_hidden_state[0] - ref).abs().max()) / float(ref.abs().max())
                 assert err <= tol, f"{mode} team of {k}, member {j} rows [{s0}, {s1}): rel err {err:.3e}"
             assert edges == parallel.sp_row_ranges(S, k) and not box.box, "every K | V block sent was received"
+        # round 6: the two halves of a sequence-parallel layer as ONE C call each (stllm_llama_layer_sp) == the per-op body, bit for bit
+        from stllm_amd.models import llama as llama_mod
+        outs = {}
+        old = llama_mod.STACK_ENTRY
+        try:
+            for flag in (True, False):
+                llama_mod.STACK_ENTRY = flag
+                box = parallel.Mailbox()
+                outs[flag] = [lm(inputs_embeds=emb, sp=dict(index=j, size=2, ranks=[0, 1], rank=j, mailbox=box)).last_hidden_state.clone() for j in range(2)]
+        finally:
+            llama_mod.STACK_ENTRY = old
+        assert all(torch.equal(a, b) for a, b in zip(outs[True], outs[False])), "stllm_llama_layer_sp vs the per-op path"
     from stllm_amd import hip
     assert hip.gemm_workspace_ok()
 
