@@ -153,6 +153,13 @@ def test_packers_are_permutations():
     oc, os_ = O.rope_tables(9, 128)
     assert torch.equal(c, oc[:, :64]) and torch.equal(s, os_[:, :64])
     assert pack.pad_rows(torch.zeros(32001, 8)).shape[0] == 32128
+    # round 6: the fragment-major copy of the W-direct GEMM (stllm_gemm_args.w_frag): lane l of fragment (nb, ks) = w[32 nb + (l & 31), 16 ks + 8 (l >> 5) : + 8]
+    w = torch.arange(64 * 48, dtype=torch.float32).view(64, 48).to(torch.bfloat16)
+    f = pack.frag32(w).view(2, 3, 64, 8)
+    for nb, ks, l in [(0, 0, 0), (0, 0, 31), (0, 0, 32), (1, 2, 63), (1, 1, 37), (0, 2, 5)]:
+        assert torch.equal(f[nb, ks, l], w[32 * nb + (l & 31), 16 * ks + 8 * (l >> 5): 16 * ks + 8 * (l >> 5) + 8])
+    assert sorted(f.reshape(-1).float().tolist()) == sorted(w.reshape(-1).float().tolist())     # a permutation
+    assert pack.frag32_or_none(w) is None        # host tensors / shapes outside the kernel's domain: no copy (the other kernels run)
 
 
 @pytest.mark.parametrize("text,video_input,mvm,vit", [(False, "all", True, "eva_clip_g"), (True, "residual", False, "eva_clip_g"),
