@@ -490,8 +490,23 @@ __device__ __forceinline__ void lds_read_tr_3pairs(const char* p, unsigned long 
                : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2) : "v"(a), "n"(OFF), "n"(OFF + 64), "n"(OFF + 128) : "memory");
 }
 
-template <typename T, int KS2, int DP = 128>
-__global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
+// NT: the launch's thread bound.  768 (12 waves: 3 per SIMD) caps the kernel at 168 registers and costs it 2-3 spilled ones; the prefill's 2 x 4 split
+// (8 waves) is instantiated with 512: 256 registers, no scratch (round 6)
+// four pairs at four addresses (the d-blocks of a SWIZZLED 256-byte row), ONE wait: eight reads in flight instead of four serialised round trips per 16-key step
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr_4pairs(const char* p0, const char* p1, const char* p2, const char* p3, unsigned long long (&lo)[4], unsigned long long (&hi)[4]) {
+  typedef __attribute__((address_space(3))) const char* lp;
+  const unsigned a0 = (unsigned)(uintptr_t)(lp)p0, a1 = (unsigned)(uintptr_t)(lp)p1, a2 = (unsigned)(uintptr_t)(lp)p2, a3 = (unsigned)(uintptr_t)(lp)p3;
+  asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+               "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+               "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+               "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(OFF) : "memory");
+}
+
+template <typename T, int KS2, int DP = 128, int NT = 768>
+__global__ __launch_bounds__(NT) void attn_dma_kernel(const AttnParams p) {
   ATTN_STAMP(0);
   // DP = 128: Llama (256-byte rows, 128-key windows); DP = 96: head_dim 88 of the EVA ViT (rows of 11 chunks in a 12-chunk = 192-byte
   // pitch, chunk 11 a copy of chunk 10 that meets zero-padded Q / unstored columns; 96-key windows, two workgroups per CU)
@@ -657,17 +672,31 @@ __global__ __launch_bounds__(768) void attn_dma_kernel(const AttnParams p) {
           i32x4 pf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) pf[e] = (int)(Elem<T>::pack2(s[a * 8 + 2 * e], s[a * 8 + 2 * e + 1]));
+          if constexpr (NT == 512 && DB == 4) {
+            // 256 registers (the 8-wave instantiation): the eight transposing reads of a 16-key step in flight together, one wait (under the 768-thread
+            // bound's 168 registers the same block spilled and measured slower: 24.8 vs 22.7 us, round 2)
+            const int row = t * 32 + 16 * a + 4 * lh + jrow;
+            const char* rp = vimg + row * PITCH;
+            auto ad = [&](int i) { const int pc8 = i * 8 + cb + piece; return rp + (((pc8 >> 1) ^ swv(row)) << 4) + ((pc8 & 1) << 3); };
+            unsigned long long lo[4], hi[4];
+            lds_read_tr_4pairs<8 * PITCH>(ad(0), ad(1), ad(2), ad(3), lo, hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const i32x4 vf = {(int)(unsigned)lo[i], (int)(unsigned)(lo[i] >> 32), (int)(unsigned)hi[i], (int)(unsigned)(hi[i] >> 32)};
+              o[i] = Elem<T>::mfma(vf, pf, o[i]);
+            }
+          } else {
 #pragma unroll
           for (int i = 0; i < DB; ++i) {
             unsigned long long lo, hi;
             {
               const int row = t * 32 + 16 * a + 4 * lh + jrow;       // (+ 8 for the second read: same row & 7)
               const int pc8 = i * 8 + cb + piece;                    // 8-byte piece of the row: column 32 i + 16 (li >> 4) + 4 piece
-              // (all eight reads of a 16-key step in one asm block with a single wait measured SLOWER: 24.8 vs 22.7 us, and spilled)
               lds_read_tr_pair<8 * PITCH>(vimg + row * PITCH + (((pc8 >> 1) ^ swv(row)) << 4) + ((pc8 & 1) << 3), lo, hi);
             }
             const i32x4 vf = {(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, (int)(unsigned)(hi >> 32)};
             o[i] = Elem<T>::mfma(vf, pf, o[i]);
+          }
           }
         }
       }
@@ -922,8 +951,8 @@ int launch_dma88(const AttnParams& p, hipStream_t stream) {
 
 // env STLLM_ATTN_DMA / option "attn_dma" (stllm_options().attn_dma): 1 (default) LDS-DMA kernels for head_dim 128 (Llama prefill) and 88 (ViT) |
                               // 0 register-staged kernels everywhere
-template <typename T, int KS2, int DP = 128>
-int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
+template <typename T, int KS2, int DP = 128, int NT = 768>
+int launch_dma_nt(const AttnParams& p, hipStream_t stream, int nw_req) {
   constexpr int W = DP == 128 ? 128 : 96;
   constexpr int lds_win = 2 * 2 * W * (DP * 2);   // two buffers of [K | V] windows (128 KiB at 128 dims, 72 KiB at 96: two workgroups per CU)
   constexpr int lds_max = DP == 128 ? 160 * 1024 : 80 * 1024;
@@ -931,7 +960,7 @@ int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
   bool attr_first;
   const int attr_d = attr_dev.enter(&attr_first);
   if (attr_first) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma_kernel<T, KS2, DP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     attr_dev.done(attr_d);
   }
   const int q_tiles = (p.Sq + 31) / 32;
@@ -947,9 +976,17 @@ int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
   const int lds = lds_win + (pp.q_lds ? q_img : 0);
   pp.merge_par = (KS2 > 1 && stllm_options().attn_q_lds != 0 && (KS2 - 1) * nw * (DP / 32 * 16 + 2) * 256 <= lds) ? 1 : 0;
   dim3 grid((q_tiles + nw - 1) / nw, p.H, p.B), block(64 * nw * KS2);
-  hipLaunchKernelGGL((attn_dma_kernel<T, KS2, DP>), grid, block, lds, stream, pp);
+  hipLaunchKernelGGL((attn_dma_kernel<T, KS2, DP, NT>), grid, block, lds, stream, pp);
   STLLM_CHECK_LAUNCH("stllm_attention(dma)");
   return STLLM_OK;
+}
+
+template <typename T, int KS2, int DP = 128>
+int launch_dma(const AttnParams& p, hipStream_t stream, int nw_req) {
+  const int q_tiles = (p.Sq + 31) / 32;
+  const int nw = nw_req < q_tiles ? nw_req : q_tiles;
+  if (64 * nw * KS2 <= 512 && stllm_options().attn_q_lds != 0) return launch_dma_nt<T, KS2, DP, 512>(p, stream, nw_req);
+  return launch_dma_nt<T, KS2, DP, 768>(p, stream, nw_req);
 }
 
 // ---- exact fp32 path: one wave per query row -----------------------------------------------------

@@ -45,6 +45,10 @@ def build(force=False):
         text = re.sub(r'const unsigned a = \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) const char\*\)p;\s*asm volatile\("ds_read_b64_tr_b16[^;]*;',
                       "l0 = emu_ds_read_tr_b16(p); h0 = emu_ds_read_tr_b16(p + OFF); l1 = emu_ds_read_tr_b16(p + 64); h1 = emu_ds_read_tr_b16(p + OFF + 64); "
                       "l2 = emu_ds_read_tr_b16(p + 128); h2 = emu_ds_read_tr_b16(p + OFF + 128);", text, count=1)
+        # ... and the four-pair block of the 8-wave prefill kernel (four addresses, one wait)
+        text = re.sub(r'typedef __attribute__\(\(address_space\(3\)\)\) const char\* lp;\s*const unsigned a0 =[^;]*;\s*asm volatile\("ds_read_b64_tr_b16[^;]*;',
+                      "lo[0] = emu_ds_read_tr_b16(p0); hi[0] = emu_ds_read_tr_b16(p0 + OFF); lo[1] = emu_ds_read_tr_b16(p1); hi[1] = emu_ds_read_tr_b16(p1 + OFF); "
+                      "lo[2] = emu_ds_read_tr_b16(p2); hi[2] = emu_ds_read_tr_b16(p2 + OFF); lo[3] = emu_ds_read_tr_b16(p3); hi[3] = emu_ds_read_tr_b16(p3 + OFF);", text, count=1)
         tu = os.path.join(OUT, f.replace(".hip", ".emu.cpp"))
         with open(tu, "w") as fh:
             fh.write(head + text)
