@@ -753,3 +753,44 @@ def test_kv_cache_decode_matches_reprefill(mode, tol):
         ids_n = model.generate(inputs_embeds=emb, max_new_tokens=3, use_cache=False)
     if mode == "fp32":
         assert torch.equal(ids_c, ids_n)
+
+
+def test_two_steps_in_flight_on_two_streams_are_bit_identical():
+    """Round 6 (bench.py's default): two independent forward() calls enqueued on two HIP streams share the chip; per-(device, stream) GEMM workspaces,
+    the stream-keyed H2D table cache and the stream-ordered allocator keep them apart — each produces exactly the logits of a forward() run alone."""
+    from stllm_amd import hip, runtime
+    cfg = dict(vit_model="eva_clip_g", image_size=224, num_query_token=32, video_input="all", use_mask=False, mvm_decode=False,
+               qformer_text_input=False, max_txt_len=32, end_sym=" 2")
+    model = build_stllm(cfg, vit_depth=2, qf_layers=2, llm_layers=2)
+    g = golden("stllm_minigpt4")
+    a = _samples_from_fixture(g, 4, False)
+    b = dict(a, image=T("input.video_b", (2, 4, 3, 224, 224)).cuda())
+    with runtime.use_dtype("bf16"):
+        ref_a, ref_b = model(samples=a).logits.clone(), model(samples=b).logits.clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                out_a = model(samples=a).logits
+            with torch.cuda.stream(s2):
+                out_b = model(samples=b).logits
+        torch.cuda.synchronize()
+    assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
+    assert not torch.equal(ref_a, ref_b)
+    assert hip.gemm_workspace_ok()
+
+
+def test_h2d_table_cache_is_keyed_by_content():
+    """Round 6: small host tables (index tables, labels, lengths) are uploaded once per content: the same bytes give the SAME device tensor (no copy in steady
+    state), other bytes another one; float tensors and large tables are never cached."""
+    from stllm_amd import hip
+    t1 = torch.arange(100, dtype=torch.int32)
+    d1, d2 = hip.h2d(t1, "cuda"), hip.h2d(t1.clone(), "cuda")
+    assert d1.data_ptr() == d2.data_ptr() and torch.equal(d1.cpu(), t1)
+    t2 = t1.clone(); t2[7] = -1
+    d3 = hip.h2d(t2, "cuda")
+    assert d3.data_ptr() != d1.data_ptr() and torch.equal(d3.cpu(), t2) and torch.equal(d1.cpu(), t1)
+    f = torch.rand(16)
+    assert hip.h2d(f, "cuda").data_ptr() != hip.h2d(f, "cuda").data_ptr()
+    big = torch.zeros(100000, dtype=torch.int32)
+    assert hip.h2d(big, "cuda").data_ptr() != hip.h2d(big, "cuda").data_ptr()
