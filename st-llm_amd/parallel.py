@@ -178,10 +178,12 @@ def play_ranks(sm, step, ranks, world, **plan_options):
     travel forward through the real mailbox (ranks in ascending order: a member only ever needs what EARLIER members of its team produced).
     Tests and bench.py's full-size check of the sequence-parallel prefill on one GPU use this."""
     pre = Mailbox(dummy=True)
-    for r in ranks:
+    sent = {}
+    for r in sorted(ranks):   # ascending in BOTH passes (ADVICE r05: a caller's [4, 0] let rank 0 pop rank 4's block off the dummy mailbox in pass 1)
         sm.set_frame_parallel(r, world, mailbox=pre, **plan_options)
         step()
-    tokens = {k: v for k, v in pre.box.items() if k[2][0] == "tok"}
+        sent.update({k: v for k, v in pre.box.items() if k[2][0] == "tok"})   # snapshot of the sends: a later rank's pass-1 receive may pop them
+    tokens = sent
     box, outs = Mailbox(), {}
     for r in sorted(ranks):
         box.box.update({k: v for k, v in tokens.items() if k[1] == r})
